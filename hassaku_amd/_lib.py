@@ -1,0 +1,97 @@
+"""ctypes binding of libhassaku_hip.so (the C ABI declared in include/hassaku_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback behind these calls.  If the shared
+object is missing, or a compute entry point is called without a GPU, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhassaku_hip.so')
+
+_lib = None
+
+
+class HskBprmfState(ctypes.Structure):
+    """Mirror of `struct hsk_bprmf_state` (include/hassaku_hip.h)."""
+    _fields_ = [
+        ('user_emb', c_void_p), ('item_emb', c_void_p), ('item_bias', c_void_p),
+        ('user_bias', c_void_p), ('global_bias', c_void_p),
+        ('m_user_emb', c_void_p), ('v_user_emb', c_void_p),
+        ('m_item_emb', c_void_p), ('v_item_emb', c_void_p),
+        ('m_item_bias', c_void_p), ('v_item_bias', c_void_p),
+        ('m_user_bias', c_void_p), ('v_user_bias', c_void_p),
+        ('m_global_bias', c_void_p), ('v_global_bias', c_void_p),
+        ('n_users', c_int64), ('n_items', c_int64), ('dim', c_int64),
+        ('lr', c_double), ('beta1', c_double), ('beta2', c_double), ('eps', c_double), ('wd', c_double),
+        ('step', c_int64),
+        ('csr_indptr', c_void_p), ('csr_indices', c_void_p),
+        ('coo_user', c_void_p), ('coo_item', c_void_p),
+        ('nnz', c_int64),
+        ('seed', c_uint64),
+        ('workspace', c_void_p), ('workspace_bytes', c_int64),
+        ('max_batch', c_int64), ('max_cols', c_int64),
+        ('lazy_users', c_int32), ('reserved0', c_int32),
+        ('loss_out', c_void_p), ('status', c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol of include/hassaku_hip.h
+SIGNATURES = {
+    'hsk_version': (c_int, []),
+    'hsk_last_error': (c_char_p, []),
+    'hsk_device_info': (c_int, [POINTER(c_int32), POINTER(c_int32), c_char_p, c_int32]),
+    'hsk_mf_scores': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_void_p, c_int64, c_int64,
+                                                              c_void_p, c_void_p, c_void_p]),
+    'hsk_bpr_loss_grad': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hsk_mf_backward': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                c_int64, c_void_p] + [c_void_p] * 5 + [c_void_p, c_void_p]),
+    'hsk_adamw_dense': (c_int, [c_void_p] * 4 + [c_int64] + [c_double] * 5 + [c_int64, c_void_p]),
+    'hsk_sample_negatives_uniform': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                             c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    'hsk_bprmf_workspace_bytes': (c_int64, [c_int64] * 5),
+    'hsk_bprmf_init_workspace': (c_int, [POINTER(HskBprmfState), c_void_p]),
+    'hsk_bprmf_train_step': (c_int, [POINTER(HskBprmfState), c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'hsk_bprmf_train_step_sampled': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64,
+                                             c_void_p]),
+    'hsk_bprmf_flush': (c_int, [POINTER(HskBprmfState), c_void_p]),
+    'hsk_bprmf_last_batch': (c_int, [POINTER(HskBprmfState), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'hsk_mf_eval_topk': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,
+                                                                 c_void_p, c_void_p, c_int64,
+                                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hsk_topk_dense': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'hsk_topk_merge': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'hsk_rank_metrics': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                 POINTER(c_int32), c_int32, c_void_p, c_void_p]),
+}
+
+
+def load():
+    """Load the shared library once and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C hassaku_amd/csrc`.  There is no CPU fallback for the HIP path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = load().hsk_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'hassaku_hip {what} failed (code {rc}): {msg}')
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('hassaku_amd: no HIP device visible; the MI355X path has no CPU fallback')

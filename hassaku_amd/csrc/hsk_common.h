@@ -1,0 +1,171 @@
+// hsk_common.h -- shared device helpers for the gfx950 kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/hassaku_hip.h"
+
+#define HSK_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// host-side error plumbing
+// ---------------------------------------------------------------------------------------------
+void hsk_set_error(const char* fmt, ...);
+
+#define HSK_REQUIRE(cond, code, ...)   \
+  do {                                 \
+    if (!(cond)) {                     \
+      hsk_set_error(__VA_ARGS__);      \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define HSK_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      hsk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return HSK_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define HSK_LAUNCH_CHECK()                                                                 \
+  do {                                                                                     \
+    hipError_t e_ = hipGetLastError();                                                     \
+    if (e_ != hipSuccess) {                                                                \
+      hsk_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return HSK_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+static inline int64_t hsk_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t hsk_align_up(int64_t a, int64_t b) { return hsk_ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ int hsk_lane() { return (int)(threadIdx.x & (HSK_WAVE - 1)); }
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float hsk_dpp_add(float v) {
+  // v + (DPP-permuted v); rows disabled by ROW_MASK contribute +0
+  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(moved);
+}
+
+// Sum over the 64 lanes of a wave; the result is wave-uniform (read from lane 63).
+__device__ __forceinline__ float hsk_wave_sum(float v) {
+  v = hsk_dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+  v = hsk_dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = hsk_dpp_add<0x141>(v);       // row_half_mirror
+  v = hsk_dpp_add<0x140>(v);       // row_mirror     -> every lane holds its 16-lane row sum
+  v = hsk_dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+  v = hsk_dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ double hsk_wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, HSK_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ int hsk_wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, HSK_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ float hsk_readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int hsk_readlane_i(int v, int lane) {
+  return __builtin_amdgcn_readlane(v, lane);
+}
+__device__ __forceinline__ int hsk_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- small fixed-width float vectors (1, 2 or 4 floats = one global_load_dword/x2/x4) ----------
+template <int V> struct hsk_vec;
+template <> struct hsk_vec<1> { float v[1]; };
+template <> struct __attribute__((aligned(8))) hsk_vec<2> { float v[2]; };
+template <> struct __attribute__((aligned(16))) hsk_vec<4> { float v[4]; };
+
+template <int V>
+__device__ __forceinline__ hsk_vec<V> hsk_ldg(const float* p) {
+  return *reinterpret_cast<const hsk_vec<V>*>(p);
+}
+template <int V>
+__device__ __forceinline__ void hsk_stg(float* p, const hsk_vec<V>& x) {
+  *reinterpret_cast<hsk_vec<V>*>(p) = x;
+}
+template <int V>
+__device__ __forceinline__ hsk_vec<V> hsk_zero() {
+  hsk_vec<V> r;
+#pragma unroll
+  for (int i = 0; i < V; ++i) r.v[i] = 0.f;
+  return r;
+}
+
+// ---- Philox4x32-10 counter RNG ---------------------------------------------------------------
+struct hsk_u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ hsk_u32x4 hsk_philox4x32_10(hsk_u32x4 ctr, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * ctr.x;
+    uint64_t p1 = (uint64_t)M1 * ctr.z;
+    hsk_u32x4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ ctr.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ ctr.w ^ k1;
+    n.w = (uint32_t)p0;
+    ctr = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return ctr;
+}
+
+// ---- AdamW scalars (host-computed exactly like torch.optim.adamw's single-tensor path) ---------
+struct hsk_adamw_consts {
+  float decay;      // 1 - lr*wd
+  float w1;         // 1 - beta1   (lerp weight)
+  float beta2;      // beta2
+  float one_m_b2;   // 1 - beta2
+  float step_size;  // lr / (1 - beta1^t)
+  float bc2_sqrt;   // sqrt(1 - beta2^t)
+  float eps;
+};
+
+__device__ __forceinline__ void hsk_adamw_update(float& p, float& m, float& v, float g,
+                                                 const hsk_adamw_consts& c) {
+  p = p * c.decay;
+  m = fmaf(c.w1, g - m, m);
+  v = fmaf(c.one_m_b2 * g, g, v * c.beta2);
+  float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p = p - c.step_size * (m / denom);
+}
+
+#endif  // __HIPCC__
+
+#ifdef __cplusplus
+#include <cmath>
+static inline hsk_adamw_consts hsk_make_adamw_consts(double lr, double b1, double b2, double eps,
+                                                     double wd, int64_t step) {
+  hsk_adamw_consts c;
+  double bc1 = 1.0 - std::pow(b1, (double)step);
+  double bc2 = 1.0 - std::pow(b2, (double)step);
+  c.decay = (float)(1.0 - lr * wd);
+  c.w1 = (float)(1.0 - b1);
+  c.beta2 = (float)b2;
+  c.one_m_b2 = (float)(1.0 - b2);
+  c.step_size = (float)(lr / bc1);
+  c.bc2_sqrt = (float)std::sqrt(bc2);
+  c.eps = (float)eps;
+  return c;
+}
+#endif

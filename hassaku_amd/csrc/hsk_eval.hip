@@ -1,0 +1,496 @@
+// hsk_eval.hip -- full-catalogue evaluation for gfx950: exact-fp32 MFMA score GEMM
+// (users x item-shard^T + biases), CSR exclusion mask, radix-select top-k, shard merge, rank metrics.
+//
+// Reference semantics restated: eval/eval.py:237-253 (scores, -inf mask), eval/eval.py:54-99
+// (topk(100), k in {100,50,10,5}), eval/metrics.py:4-105 (precision / recall / ndcg).
+#include "hsk_common.h"
+
+#include <type_traits>
+
+typedef float hsk_f32x16 __attribute__((ext_vector_type(16)));
+
+// =============================================================================================
+// Score GEMM.  C[r, j] = sum_d U[u[r], d] * I[item_begin + j, d]  (+ biases), fp32 in, fp32 acc.
+// Block tile 128 (users) x 128 (items) x 32 (k); 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of
+// v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain per output).  Both operands are
+// k-contiguous in HBM; tiles are staged [row][32+4] in LDS (144-B rows: ds_read_b128 conflict-free)
+// and each lane half h reads k = 16h .. 16h+15 of the tile, four floats per ds_read_b128, so MFMA
+// step t multiplies k = t (half 0) and k = 16+t (half 1): a fixed permutation of the k order.
+// =============================================================================================
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 32
+#define GEMM_LDS_STRIDE (GEMM_BK + 4)
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Uw, const float* __restrict__ Iw,
+                                                    const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                    const float* __restrict__ gb, int n_users, int D,
+                                                    const int64_t* __restrict__ u_idx, int n_rows, long long item_begin,
+                                                    int item_count, float* __restrict__ C, int32_t* status) {
+  __shared__ __attribute__((aligned(16))) float As[GEMM_BM * GEMM_LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Bs[GEMM_BN * GEMM_LDS_STRIDE];
+  __shared__ int urow[GEMM_BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GEMM_BM;
+  const int n0 = blockIdx.x * GEMM_BN;
+
+  if (tid < GEMM_BM) {
+    int r = m0 + tid;
+    int u = 0;
+    if (r < n_rows) {
+      long long uu = u_idx[r];
+      if (uu < 0 || uu >= n_users) {
+        if (status) atomicOr(status, HSK_STATUS_BAD_INDEX);
+        uu = 0;
+      }
+      u = (int)uu;
+    }
+    urow[tid] = u;
+  }
+  __syncthreads();
+
+  hsk_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // staging assignment: 8 threads cover the 32 floats (128 B) of one row; 32 rows per pass, 4 passes
+  const int srow = tid >> 3;
+  const int scol = (tid & 7) * 4;
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+
+  for (int k0 = 0; k0 < D; k0 += GEMM_BK) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = srow + pass * 32;
+      // A: user rows (gathered through urow)
+      {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + r < n_rows) {
+          const float* src = Uw + (long long)urow[r] * D + k0 + scol;
+          if (VEC4) {
+            if (k0 + scol < D) v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (k0 + scol + 0 < D) v.x = src[0];
+            if (k0 + scol + 1 < D) v.y = src[1];
+            if (k0 + scol + 2 < D) v.z = src[2];
+            if (k0 + scol + 3 < D) v.w = src[3];
+          }
+        }
+        *reinterpret_cast<float4*>(&As[r * GEMM_LDS_STRIDE + scol]) = v;
+      }
+      // B: item rows of the shard
+      {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + r < item_count) {
+          const float* src = Iw + (item_begin + n0 + r) * (long long)D + k0 + scol;
+          if (VEC4) {
+            if (k0 + scol < D) v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (k0 + scol + 0 < D) v.x = src[0];
+            if (k0 + scol + 1 < D) v.y = src[1];
+            if (k0 + scol + 2 < D) v.z = src[2];
+            if (k0 + scol + 3 < D) v.w = src[3];
+          }
+        }
+        *reinterpret_cast<float4*>(&Bs[r * GEMM_LDS_STRIDE + scol]) = v;
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + l32) * GEMM_LDS_STRIDE + half * 16 + q * 4]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + j * 32 + l32) * GEMM_LDS_STRIDE + half * 16 + q * 4]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const float gbv = gb ? gb[0] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l32;
+      if (col >= item_count) continue;
+      const float ib = Ib ? Ib[item_begin + col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rloc = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        const int row = m0 + rloc;
+        if (row < n_rows) {
+          float o = acc[i][j][q];
+          if (Ub) o += Ub[urow[rloc]];  // reference order: += u_bias, += i_bias, += global_bias
+          if (Ib) o += ib;
+          if (gb) o += gbv;
+          C[(long long)row * item_count + col] = o;
+        }
+      }
+    }
+}
+
+// excluded (user, item) pairs -> -inf.  One wave per eval row, lanes stride over the user's CSR row.
+__global__ __launch_bounds__(256) void k_mask_excluded(const int64_t* __restrict__ u_idx, int n_rows, int n_users,
+                                                       const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices, long long item_begin,
+                                                       int item_count, float* __restrict__ C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  long long u = u_idx[r];
+  if (u < 0 || u >= n_users) u = 0;
+  const long long lo = indptr[u], hi = indptr[u + 1];
+  for (long long e = lo + lane; e < hi; e += 64) {
+    const long long it = (long long)indices[e] - item_begin;
+    if (it >= 0 && it < item_count) C[(long long)r * item_count + it] = -INFINITY;
+  }
+}
+
+// =============================================================================================
+// Top-k per row: 4-pass 8-bit radix select on order-preserving keys, collect, bitonic sort.
+// Order: value descending, then index ascending.  One 256-thread block per row.
+// =============================================================================================
+__device__ __forceinline__ uint32_t hsk_f2key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // ascending float order == ascending key order
+}
+__device__ __forceinline__ float hsk_key2f(uint32_t k) {
+  const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(b);
+}
+
+#define TOPK_MAX 1024
+
+// sorts n (power of two, <= TOPK_MAX... up to 4096) composite keys in LDS descending
+__device__ void hsk_bitonic_desc(unsigned long long* s, int n) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = s[lo], b = s[hi];
+        if ((a < b) == desc) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <typename IdxOut>
+__global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, long long ld, int cols, int k,
+                                                   int kpad, long long idx_offset, float* __restrict__ out_vals,
+                                                   IdxOut* __restrict__ out_idx) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned long long cand[TOPK_MAX];
+  __shared__ unsigned int sh_prefix, sh_need, sh_ngt, sh_neq, sh_taken;
+  __shared__ unsigned int wave_cnt[4];
+
+  const int tid = threadIdx.x;
+  const float* __restrict__ row = X + (long long)blockIdx.x * ld;
+
+  uint32_t prefix = 0, prefix_mask = 0;
+  unsigned int need = (unsigned)k;  // how many still to take among keys matching the prefix
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int c = tid; c < cols; c += 256) {
+      const uint32_t key = hsk_f2key(row[c]);
+      if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int cum = 0;
+      int bin = 255;
+      for (; bin > 0; --bin) {
+        if (cum + hist[bin] >= need) break;
+        cum += hist[bin];
+      }
+      sh_prefix = prefix | ((uint32_t)bin << shift);
+      sh_need = need - cum;
+      sh_neq = hist[bin];
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    need = sh_need;
+    prefix_mask |= (0xffu << shift);
+    __syncthreads();
+  }
+  // prefix == key of the k-th largest element (T); `need` of the sh_neq elements equal to T are taken
+  const uint32_t T = prefix;
+  const unsigned int n_eq = sh_neq;
+  if (tid == 0) {
+    sh_ngt = 0;
+    sh_taken = 0;
+  }
+  for (int c = tid; c < kpad; c += 256) cand[c] = 0ull;  // pads sort last
+  __syncthreads();
+  const unsigned int n_gt = (unsigned)k - need;
+
+  if (n_eq == need) {
+    // no tie straddles the cut: take every key >= T, any order
+    for (int c = tid; c < cols; c += 256) {
+      const uint32_t key = hsk_f2key(row[c]);
+      if (key >= T) {
+        const unsigned int slot = atomicAdd(&sh_ngt, 1u);
+        cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)c);
+      }
+    }
+  } else {
+    // ties at the cut: keys > T in any order, keys == T lowest index first
+    for (int c = tid; c < cols; c += 256) {
+      const uint32_t key = hsk_f2key(row[c]);
+      if (key > T) {
+        const unsigned int slot = atomicAdd(&sh_ngt, 1u);
+        cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)c);
+      }
+    }
+    __syncthreads();
+    for (int base = 0; base < cols; base += 256) {
+      if (sh_taken >= need) break;  // uniform: sh_taken only changes between barriers
+      const int c = base + tid;
+      const bool eq = (c < cols) && (hsk_f2key(row[c]) == T);
+      const unsigned long long m = __ballot(eq);
+      const int lane = tid & 63, w = tid >> 6;
+      if (lane == 0) wave_cnt[w] = (unsigned)__popcll(m);
+      __syncthreads();
+      unsigned int before = sh_taken;
+      for (int ww = 0; ww < w; ++ww) before += wave_cnt[ww];
+      const unsigned int rank = before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+      if (eq && rank < need) cand[n_gt + rank] = ((unsigned long long)T << 32) | (uint32_t)(~(uint32_t)c);
+      __syncthreads();
+      if (tid == 0) sh_taken += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  hsk_bitonic_desc(cand, kpad);
+  for (int c = tid; c < k; c += 256) {
+    const unsigned long long v = cand[c];
+    out_vals[(long long)blockIdx.x * k + c] = hsk_key2f((uint32_t)(v >> 32));
+    out_idx[(long long)blockIdx.x * k + c] = (IdxOut)((long long)(~(uint32_t)v) + idx_offset);
+  }
+}
+
+static int hsk_next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// merge of candidate lists: [n_parts, rows, k] -> [rows, k]
+__global__ __launch_bounds__(256) void k_topk_merge(const float* __restrict__ vals, const int32_t* __restrict__ idx,
+                                                    int n_parts, int rows, int k, int npad,
+                                                    float* __restrict__ out_vals, int32_t* __restrict__ out_idx) {
+  __shared__ unsigned long long cand[4096];
+  const int r = blockIdx.x;
+  const int total = n_parts * k;
+  for (int c = threadIdx.x; c < npad; c += 256) {
+    unsigned long long v = 0ull;
+    if (c < total) {
+      const int p = c / k, j = c - p * k;
+      const long long src = ((long long)p * rows + r) * k + j;
+      v = ((unsigned long long)hsk_f2key(vals[src]) << 32) | (uint32_t)(~(uint32_t)idx[src]);
+    }
+    cand[c] = v;
+  }
+  hsk_bitonic_desc(cand, npad);
+  for (int c = threadIdx.x; c < k; c += 256) {
+    const unsigned long long v = cand[c];
+    out_vals[(long long)r * k + c] = hsk_key2f((uint32_t)(v >> 32));
+    out_idx[(long long)r * k + c] = (int32_t)(~(uint32_t)v);
+  }
+}
+
+// =============================================================================================
+// rank metrics: one wave per evaluated user
+// =============================================================================================
+#define HSK_MAX_KS 8
+struct hsk_ks {
+  int k[HSK_MAX_KS];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_rank_metrics(const int32_t* __restrict__ topk, int n_rows, int k_max,
+                                                      const int64_t* __restrict__ u_idx, int n_users,
+                                                      const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices, hsk_ks ks,
+                                                      float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  long long u = u_idx[r];
+  if (u < 0 || u >= n_users) u = 0;
+  const long long lo = indptr[u], hi = indptr[u + 1];
+  const int n_rel = (int)(hi - lo);
+  float hits[HSK_MAX_KS], dcg[HSK_MAX_KS], idcg[HSK_MAX_KS];
+#pragma unroll
+  for (int t = 0; t < HSK_MAX_KS; ++t) hits[t] = dcg[t] = idcg[t] = 0.f;
+  for (int rank = lane; rank < k_max; rank += 64) {
+    const int item = topk[(long long)r * k_max + rank];
+    long long l = lo, h = hi;
+    while (l < h) {
+      const long long mid = (l + h) >> 1;
+      if (indices[mid] < item)
+        l = mid + 1;
+      else
+        h = mid;
+    }
+    const bool hit = (l < hi) && (indices[l] == item);
+    const float disc = 1.f / log2f((float)(rank + 2));
+#pragma unroll
+    for (int t = 0; t < HSK_MAX_KS; ++t) {
+      if (t < ks.n && rank < ks.k[t]) {
+        if (hit) {
+          hits[t] += 1.f;
+          dcg[t] += disc;
+        }
+        if (rank < n_rel) idcg[t] += disc;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < HSK_MAX_KS; ++t) {
+    if (t < ks.n) {
+      const float h_ = hsk_wave_sum(hits[t]);
+      const float d_ = hsk_wave_sum(dcg[t]);
+      const float i_ = hsk_wave_sum(idcg[t]);
+      if (lane == 0) {
+        float* o = out + ((long long)r * ks.n + t) * 3;
+        o[0] = h_ / (float)ks.k[t];
+        o[1] = n_rel > 0 ? h_ / (float)n_rel : 0.f;
+        o[2] = n_rel > 0 ? fminf(d_ / i_, 1.f) : 0.f;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+static int hsk_launch_topk_i32(const float* X, int64_t rows, int64_t cols, int64_t ld, int64_t k, long long off,
+                               float* out_vals, int32_t* out_idx, hipStream_t stream) {
+  const int kpad = hsk_next_pow2((int)k);
+  k_topk_rows<int32_t><<<(unsigned)rows, 256, 0, stream>>>(X, ld, (int)cols, (int)k, kpad, off, out_vals, out_idx);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+extern "C" int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, const float* item_bias,
+                                const float* user_bias, const float* global_bias, int64_t n_users, int64_t n_items,
+                                int64_t dim, const int64_t* u_idx, int64_t n_rows, int64_t item_begin,
+                                int64_t item_count, const int64_t* excl_indptr, const int32_t* excl_indices, int64_t k,
+                                float* scores_ws, float* out_vals, int32_t* out_idx, int32_t* status,
+                                hsk_stream_t stream_) {
+  HSK_REQUIRE(user_emb && item_emb && u_idx && scores_ws, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_users > 0 && n_items > 0 && dim > 0, HSK_ERR_INVALID, "bad table shape");
+  HSK_REQUIRE(item_begin >= 0 && item_count > 0 && item_begin + item_count <= n_items, HSK_ERR_INVALID,
+              "item shard [%lld, +%lld) outside [0, %lld)", (long long)item_begin, (long long)item_count,
+              (long long)n_items);
+  HSK_REQUIRE(n_rows >= 0 && item_count < 0x7fffffff && n_rows < 0x7fffffff, HSK_ERR_INVALID, "bad n_rows");
+  HSK_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), HSK_ERR_INVALID,
+              "exclude CSR needs both indptr and indices");
+  HSK_REQUIRE(k >= 0 && k <= TOPK_MAX, HSK_ERR_UNSUPPORTED, "k %lld outside [0, %d]", (long long)k, TOPK_MAX);
+  HSK_REQUIRE(k <= item_count, HSK_ERR_INVALID, "k %lld > item_count %lld", (long long)k, (long long)item_count);
+  HSK_REQUIRE(k == 0 || (out_vals && out_idx), HSK_ERR_INVALID, "top-k outputs must not be NULL");
+  if (n_rows == 0) return HSK_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid((unsigned)hsk_ceil_div(item_count, GEMM_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_BM));
+  const bool vec4 = (dim % 4 == 0) && ((((uintptr_t)user_emb | (uintptr_t)item_emb) & 15) == 0);
+  if (vec4)
+    k_score_gemm<true><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
+                                                 (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
+                                                 scores_ws, status);
+  else
+    k_score_gemm<false><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
+                                                  (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
+                                                  scores_ws, status);
+  HSK_LAUNCH_CHECK();
+  if (excl_indptr) {
+    k_mask_excluded<<<(unsigned)hsk_ceil_div(n_rows, 4), 256, 0, stream>>>(
+        u_idx, (int)n_rows, (int)n_users, excl_indptr, excl_indices, (long long)item_begin, (int)item_count, scores_ws);
+    HSK_LAUNCH_CHECK();
+  }
+  if (k > 0)
+    return hsk_launch_topk_i32(scores_ws, n_rows, item_count, item_count, k, (long long)item_begin, out_vals, out_idx,
+                               stream);
+  return HSK_OK;
+}
+
+extern "C" int hsk_topk_dense(const float* logits, int64_t rows, int64_t cols, int64_t ld, int64_t k, float* out_vals,
+                              int64_t* out_idx, hsk_stream_t stream_) {
+  HSK_REQUIRE(logits && out_vals && out_idx, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && cols < 0x7fffffff, HSK_ERR_INVALID, "bad matrix shape");
+  HSK_REQUIRE(k >= 1 && k <= TOPK_MAX, HSK_ERR_UNSUPPORTED, "k %lld outside [1, %d]", (long long)k, TOPK_MAX);
+  HSK_REQUIRE(k <= cols, HSK_ERR_INVALID, "k %lld > cols %lld", (long long)k, (long long)cols);
+  if (rows == 0) return HSK_OK;
+  const int kpad = hsk_next_pow2((int)k);
+  k_topk_rows<int64_t><<<(unsigned)rows, 256, 0, (hipStream_t)stream_>>>(logits, ld, (int)cols, (int)k, kpad, 0ll,
+                                                                          out_vals, out_idx);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+extern "C" int hsk_topk_merge(const float* vals, const int32_t* idx, int64_t n_parts, int64_t rows, int64_t k,
+                              float* out_vals, int32_t* out_idx, hsk_stream_t stream_) {
+  HSK_REQUIRE(vals && idx && out_vals && out_idx, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_parts >= 1 && rows >= 0 && k >= 1, HSK_ERR_INVALID, "bad sizes");
+  HSK_REQUIRE(n_parts * k <= 4096, HSK_ERR_UNSUPPORTED, "n_parts*k = %lld > 4096", (long long)(n_parts * k));
+  if (rows == 0) return HSK_OK;
+  const int npad = hsk_next_pow2((int)(n_parts * k));
+  k_topk_merge<<<(unsigned)rows, 256, 0, (hipStream_t)stream_>>>(vals, idx, (int)n_parts, (int)rows, (int)k, npad,
+                                                                 out_vals, out_idx);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+extern "C" int hsk_rank_metrics(const int32_t* topk_idx, int64_t n_rows, int64_t k_max, const int64_t* u_idx,
+                                int64_t n_users, const int64_t* label_indptr, const int32_t* label_indices, const int32_t* ks,
+                                int32_t n_ks, float* out, hsk_stream_t stream_) {
+  HSK_REQUIRE(topk_idx && u_idx && label_indptr && label_indices && ks && out, HSK_ERR_INVALID,
+              "NULL pointer argument");
+  HSK_REQUIRE(n_ks >= 1 && n_ks <= HSK_MAX_KS, HSK_ERR_UNSUPPORTED, "n_ks %d outside [1, %d]", n_ks, HSK_MAX_KS);
+  HSK_REQUIRE(n_rows >= 0 && k_max >= 1 && n_users > 0 && n_users < 0x7fffffff, HSK_ERR_INVALID, "bad sizes");
+  hsk_ks kk;
+  kk.n = n_ks;
+  for (int t = 0; t < HSK_MAX_KS; ++t) kk.k[t] = 0;
+  for (int t = 0; t < n_ks; ++t) {
+    HSK_REQUIRE(ks[t] >= 1 && ks[t] <= k_max, HSK_ERR_INVALID, "ks[%d]=%d outside [1, k_max=%lld]", t, ks[t],
+                (long long)k_max);
+    kk.k[t] = ks[t];
+  }
+  if (n_rows == 0) return HSK_OK;
+  k_rank_metrics<<<(unsigned)hsk_ceil_div(n_rows, 4), 256, 0, (hipStream_t)stream_>>>(
+      topk_idx, (int)n_rows, (int)k_max, u_idx, (int)n_users, label_indptr, label_indices, kk, out);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}

@@ -1,0 +1,96 @@
+"""Synthetic interaction data in the reference's on-disk layout.
+
+The reference ships no processed dataset (its processors download from the network), so tests and
+bench.py use data generated here: Zipf-like item popularity, Poisson user activity, and the
+reference's per-user 80/10/10 "temporal" split sizes (n_test = ceil(.1 n), n_val = ceil(.1 n), see
+split_temporal_order_ratio_based, data/data_utils.py:241-277).  `write_csv_dataset` emits the five
+CSV files RecDataset expects (data/dataset.py:10-23).
+"""
+import math
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+# shapes named after the BASELINE.json configs (users, items, target number of interactions)
+SHAPES = {
+    'ml100k': (943, 1682, 55_000),
+    'ml1m': (6040, 3706, 575_000),
+    'ml10m': (69_878, 10_677, 8_000_000),
+    'lfm2b': (16_384, 131_072, 2_000_000),
+}
+
+
+@dataclass
+class SyntheticInteractions:
+    n_users: int
+    n_items: int
+    train: np.ndarray  # [n, 2] int64 (user_idx, item_idx), grouped by user
+    val: np.ndarray
+    test: np.ndarray
+    user_group: Optional[np.ndarray] = None  # [n_users] int64 or None
+
+
+def _sample_user_items(rng, logp, counts, chunk=512):
+    """Weighted sampling without replacement for many users at once (Gumbel top-n)."""
+    n_items = logp.shape[0]
+    out = []
+    for lo in range(0, len(counts), chunk):
+        c = counts[lo:lo + chunk]
+        keys = logp[None, :] + rng.gumbel(size=(len(c), n_items))
+        kmax = int(c.max())
+        top = np.argpartition(-keys, kmax - 1, axis=1)[:, :kmax]
+        # order the kept ones by key so that the first c[i] are the c[i] best
+        order = np.argsort(-np.take_along_axis(keys, top, axis=1), axis=1)
+        top = np.take_along_axis(top, order, axis=1)
+        for i, n in enumerate(c):
+            out.append(top[i, :n])
+    return out
+
+
+def generate(n_users: int, n_items: int, n_interactions: int, seed: int = 0, n_groups: int = 0,
+             min_per_user: int = 10) -> SyntheticInteractions:
+    rng = np.random.default_rng(seed)
+    pop = np.arange(1, n_items + 1, dtype=np.float64) ** -0.8
+    pop = pop[rng.permutation(n_items)]
+    logp = np.log(pop / pop.sum())
+    lam = n_interactions / n_users
+    counts = rng.poisson(lam, size=n_users)
+    counts = np.clip(counts, min_per_user, max(min_per_user, n_items // 2)).astype(np.int64)
+    per_user = _sample_user_items(rng, logp, counts)
+    tr, va, te = [], [], []
+    for u, items in enumerate(per_user):
+        items = items[rng.permutation(len(items))]  # the "temporal" order
+        n = len(items)
+        n_test = math.ceil(n * 0.1)
+        n_val = math.ceil(n * 0.1)
+        n_train = n - n_val - n_test
+        uu = np.full(n, u, dtype=np.int64)
+        tr.append(np.stack([uu[:n_train], items[:n_train]], 1))
+        va.append(np.stack([uu[n_train:n_train + n_val], items[n_train:n_train + n_val]], 1))
+        te.append(np.stack([uu[n - n_test:], items[n - n_test:]], 1))
+    group = rng.integers(0, n_groups, size=n_users) if n_groups > 0 else None
+    return SyntheticInteractions(n_users, n_items, np.concatenate(tr).astype(np.int64),
+                                 np.concatenate(va).astype(np.int64), np.concatenate(te).astype(np.int64), group)
+
+
+def generate_named(name: str, seed: int = 0, n_groups: int = 0) -> SyntheticInteractions:
+    u, i, n = SHAPES[name]
+    return generate(u, i, n, seed=seed, n_groups=n_groups)
+
+
+def write_csv_dataset(data: SyntheticInteractions, path: str):
+    """user_idxs.csv, item_idxs.csv, listening_history_{train,val,test}.csv (data/dataset.py:10-23)."""
+    import pandas as pd
+    os.makedirs(path, exist_ok=True)
+    users = pd.DataFrame({'user_idx': np.arange(data.n_users)})
+    if data.user_group is not None:
+        users['group_idx'] = data.user_group
+    users.to_csv(os.path.join(path, 'user_idxs.csv'), index=False)
+    pd.DataFrame({'item_idx': np.arange(data.n_items)}).to_csv(os.path.join(path, 'item_idxs.csv'), index=False)
+    for split in ('train', 'val', 'test'):
+        arr = getattr(data, split)
+        pd.DataFrame({'user_idx': arr[:, 0], 'item_idx': arr[:, 1]}).to_csv(
+            os.path.join(path, f'listening_history_{split}.csv'), index=False)
+    return path

@@ -1,0 +1,349 @@
+"""Thin torch-tensor front end over the C ABI (include/hassaku_hip.h).
+
+PyTorch is used here only as the owner of device memory and streams; every computation is a HIP
+kernel of libhassaku_hip.so.  Shapes are validated on the host before any pointer is handed over.
+"""
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from hassaku_amd import _lib
+from hassaku_amd._lib import HskBprmfState
+
+ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-8  # torch.optim.AdamW defaults (train/trainer.py:52-53)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Optional[torch.Tensor], dtype, name: str, shape: Optional[Tuple[int, ...]] = None, optional=False):
+    if t is None:
+        if optional:
+            return
+        raise ValueError(f'{name} must not be None')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must live on the HIP device (got {t.device}); there is no CPU path')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f'{name} has shape {tuple(t.shape)}, expected {tuple(shape)}')
+
+
+def new_status(device) -> torch.Tensor:
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def raise_on_status(status: torch.Tensor, what: str = ''):
+    """Synchronising check of the device status word."""
+    s = int(status.item())
+    if s & 1:
+        raise IndexError(f'{what}: index out of range in self')
+    if s & 2:
+        raise RuntimeError(f'{what}: negative sampler gave up (a user interacted with ~every item)')
+
+
+# ------------------------------------------------------------------------------------------------
+# un-fused operators
+# ------------------------------------------------------------------------------------------------
+def mf_scores(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, i_idx, status=None):
+    """logits[b,k] = <U[u_b], I[i_bk]> + biases.  u_idx [B] int64, i_idx [B,K] int64 -> [B,K] fp32."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    n_users, dim = user_emb.shape
+    n_items = item_emb.shape[0]
+    _chk(user_emb, torch.float32, 'user_emb')
+    _chk(item_emb, torch.float32, 'item_emb', (n_items, dim))
+    _chk(item_bias, torch.float32, 'item_bias', optional=True)
+    _chk(user_bias, torch.float32, 'user_bias', optional=True)
+    _chk(global_bias, torch.float32, 'global_bias', optional=True)
+    if item_bias is not None and item_bias.numel() != n_items:
+        raise ValueError('item_bias size mismatch')
+    if user_bias is not None and user_bias.numel() != n_users:
+        raise ValueError('user_bias size mismatch')
+    _chk(u_idx, torch.int64, 'u_idx')
+    _chk(i_idx, torch.int64, 'i_idx')
+    if u_idx.dim() != 1 or i_idx.dim() != 2 or i_idx.shape[0] != u_idx.shape[0]:
+        raise ValueError(f'u_idx {tuple(u_idx.shape)} / i_idx {tuple(i_idx.shape)}: expected [B] and [B,K]')
+    B, K = i_idx.shape
+    out = torch.empty((B, K), dtype=torch.float32, device=user_emb.device)
+    # the kernel takes at most 65535 rows per launch
+    for lo in range(0, B, 65535):
+        hi = min(B, lo + 65535)
+        _lib.check(lib.hsk_mf_scores(_p(user_emb), _p(item_emb), _p(item_bias), _p(user_bias), _p(global_bias),
+                                     n_users, n_items, dim, _p(u_idx[lo:hi]), _p(i_idx[lo:hi]), hi - lo, K,
+                                     _p(out[lo:hi]), _p(status), _stream()), 'hsk_mf_scores')
+    return out
+
+
+def bpr_loss_grad(logits: torch.Tensor, need_grad: bool = True):
+    """-> (loss fp64 [1], grad_logits fp32 [B,K] or None)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(logits, torch.float32, 'logits')
+    if logits.dim() != 2 or logits.shape[1] < 2 or logits.shape[0] < 1:
+        raise ValueError(f'logits must be [B>=1, K>=2], got {tuple(logits.shape)}')
+    B, K = logits.shape
+    loss = torch.empty(1, dtype=torch.float64, device=logits.device)
+    ws = torch.empty(B, dtype=torch.float64, device=logits.device)
+    grad = torch.empty_like(logits) if need_grad else None
+    _lib.check(lib.hsk_bpr_loss_grad(_p(logits), B, K, _p(loss), _p(grad), _p(ws), _stream()), 'hsk_bpr_loss_grad')
+    return loss, grad
+
+
+def mf_backward(user_emb, item_emb, u_idx, i_idx, grad_logits, want_item_bias, want_user_bias, want_global_bias,
+                status=None):
+    """Dense parameter gradients (what embedding_dense_backward would give)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    n_users, dim = user_emb.shape
+    n_items = item_emb.shape[0]
+    _chk(user_emb, torch.float32, 'user_emb')
+    _chk(item_emb, torch.float32, 'item_emb', (n_items, dim))
+    _chk(u_idx, torch.int64, 'u_idx')
+    _chk(i_idx, torch.int64, 'i_idx')
+    B, K = i_idx.shape
+    _chk(grad_logits, torch.float32, 'grad_logits', (B, K))
+    if u_idx.shape != (B,):
+        raise ValueError('u_idx / i_idx batch mismatch')
+    if B > 65535:
+        raise ValueError('mf_backward handles at most 65535 rows per call')
+    dev = user_emb.device
+    g_u = torch.empty_like(user_emb)
+    g_i = torch.empty_like(item_emb)
+    g_ib = torch.empty(n_items, dtype=torch.float32, device=dev) if want_item_bias else None
+    g_ub = torch.empty(n_users, dtype=torch.float32, device=dev) if want_user_bias else None
+    g_gb = torch.empty(1, dtype=torch.float32, device=dev) if want_global_bias else None
+    _lib.check(lib.hsk_mf_backward(_p(user_emb), _p(item_emb), n_users, n_items, dim, _p(u_idx), _p(i_idx), B, K,
+                                   _p(grad_logits), _p(g_u), _p(g_i), _p(g_ib), _p(g_ub), _p(g_gb), _p(status),
+                                   _stream()), 'hsk_mf_backward')
+    return g_u, g_i, g_ib, g_ub, g_gb
+
+
+def adamw_dense(p, g, m, v, lr, wd, step, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
+    """In-place dense AdamW step (step is 1-based)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(p, torch.float32, 'p')
+    _chk(m, torch.float32, 'm', tuple(p.shape))
+    _chk(v, torch.float32, 'v', tuple(p.shape))
+    _chk(g, torch.float32, 'g', tuple(p.shape), optional=True)
+    _lib.check(lib.hsk_adamw_dense(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step, _stream()),
+               'hsk_adamw_dense')
+
+
+def sample_negatives_uniform(csr_indptr, csr_indices, n_items, u_idx, n_neg, seed, stream_id=0, status=None):
+    """neg[b,n] ~ U{[0,n_items) minus the CSR row of u_b}.  -> int64 [B, n_neg]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(csr_indptr, torch.int64, 'csr_indptr')
+    _chk(csr_indices, torch.int32, 'csr_indices')
+    _chk(u_idx, torch.int64, 'u_idx')
+    n_users = csr_indptr.numel() - 1
+    B = u_idx.numel()
+    out = torch.empty((B, n_neg), dtype=torch.int64, device=u_idx.device)
+    _lib.check(lib.hsk_sample_negatives_uniform(_p(csr_indptr), _p(csr_indices), n_users, n_items, _p(u_idx), B, n_neg,
+                                                seed, stream_id, _p(out), _p(status), _stream()),
+               'hsk_sample_negatives_uniform')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fused training step
+# ------------------------------------------------------------------------------------------------
+class BprMfFusedState:
+    """Owns the torch tensors the C `hsk_bprmf_state` points at (moments, workspace, loss, status).
+
+    Parameters are borrowed from the model (`nn.Parameter.data`), so state_dict()/model.pth see
+    every update.  One instance per (model, optimizer hyper-parameters).
+    """
+
+    def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
+                 max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, seed=0,
+                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        n_users, dim = user_emb.shape
+        n_items = item_emb.shape[0]
+        _chk(user_emb, torch.float32, 'user_emb')
+        _chk(item_emb, torch.float32, 'item_emb', (n_items, dim))
+        for t, name, n in ((item_bias, 'item_bias', n_items), (user_bias, 'user_bias', n_users),
+                           (global_bias, 'global_bias', 1)):
+            _chk(t, torch.float32, name, optional=True)
+            if t is not None and t.numel() != n:
+                raise ValueError(f'{name} has {t.numel()} elements, expected {n}')
+        dev = user_emb.device
+        self.device = dev
+        self.params = dict(user_emb=user_emb, item_emb=item_emb, item_bias=item_bias, user_bias=user_bias,
+                           global_bias=global_bias)
+        self.m = {k: (torch.zeros_like(t) if t is not None else None) for k, t in self.params.items()}
+        self.v = {k: (torch.zeros_like(t) if t is not None else None) for k, t in self.params.items()}
+        self.loss_out = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.max_batch, self.max_cols = int(max_batch), int(max_cols)
+        nbytes = self.lib.hsk_bprmf_workspace_bytes(n_users, n_items, dim, self.max_batch, self.max_cols)
+        if nbytes <= 0:
+            raise ValueError('invalid workspace request')
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.csr_indptr, self.csr_indices, self.coo_user, self.coo_item = csr_indptr, csr_indices, coo_user, coo_item
+        if csr_indptr is not None:
+            _chk(csr_indptr, torch.int64, 'csr_indptr', (n_users + 1,))
+            _chk(csr_indices, torch.int32, 'csr_indices')
+            _chk(coo_user, torch.int32, 'coo_user')
+            _chk(coo_item, torch.int32, 'coo_item', tuple(coo_user.shape))
+
+        st = HskBprmfState()
+        for k, t in self.params.items():
+            setattr(st, k, _p(t))
+            setattr(st, 'm_' + k, _p(self.m[k]))
+            setattr(st, 'v_' + k, _p(self.v[k]))
+        st.n_users, st.n_items, st.dim = n_users, n_items, dim
+        st.lr, st.beta1, st.beta2, st.eps, st.wd = lr, beta1, beta2, eps, wd
+        st.step = 0
+        st.csr_indptr, st.csr_indices = _p(csr_indptr), _p(csr_indices)
+        st.coo_user, st.coo_item = _p(coo_user), _p(coo_item)
+        st.nnz = 0 if coo_user is None else coo_user.numel()
+        st.seed = seed & 0xFFFFFFFFFFFFFFFF
+        st.workspace, st.workspace_bytes = _p(self.workspace), nbytes
+        st.max_batch, st.max_cols = self.max_batch, self.max_cols
+        st.lazy_users = 0
+        st.loss_out, st.status = _p(self.loss_out), _p(self.status)
+        self.st = st
+        _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(st), _stream()), 'hsk_bprmf_init_workspace')
+
+    @property
+    def step_count(self) -> int:
+        return int(self.st.step)
+
+    def step(self, u_idx: torch.Tensor, i_idx: torch.Tensor):
+        """One fused step on a loader-provided batch (u_idx [B] int64, i_idx [B,1+N] int64)."""
+        _chk(u_idx, torch.int64, 'u_idx')
+        _chk(i_idx, torch.int64, 'i_idx')
+        if i_idx.dim() != 2 or u_idx.shape != (i_idx.shape[0],):
+            raise ValueError(f'u_idx {tuple(u_idx.shape)} / i_idx {tuple(i_idx.shape)}: expected [B] and [B,1+N]')
+        B, K = i_idx.shape
+        _lib.check(self.lib.hsk_bprmf_train_step(ctypes.byref(self.st), _p(u_idx), _p(i_idx), B, K, _stream()),
+                   'hsk_bprmf_train_step')
+
+    def step_sampled(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int):
+        """One fused step; positives = interactions order[start:start+batch], negatives drawn on device."""
+        if order is not None:
+            _chk(order, torch.int64, 'order')
+            if start + batch > order.numel():
+                raise ValueError('order too short')
+        _lib.check(self.lib.hsk_bprmf_train_step_sampled(ctypes.byref(self.st), _p(order), start, batch, n_neg,
+                                                         _stream()), 'hsk_bprmf_train_step_sampled')
+
+    def last_batch(self, batch: int, n_cols: int):
+        u = torch.empty(batch, dtype=torch.int64, device=self.device)
+        i = torch.empty((batch, n_cols), dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.hsk_bprmf_last_batch(ctypes.byref(self.st), batch, n_cols, _p(u), _p(i), _stream()),
+                   'hsk_bprmf_last_batch')
+        return u, i
+
+    def flush(self):
+        _lib.check(self.lib.hsk_bprmf_flush(ctypes.byref(self.st), _stream()), 'hsk_bprmf_flush')
+
+    def last_loss(self) -> float:
+        return float(self.loss_out[0].item())
+
+    def pop_loss_sum(self) -> float:
+        """Sum of the per-step losses since the last call (one host sync)."""
+        s = float(self.loss_out[1].item())
+        self.loss_out[1].zero_()
+        return s
+
+    def check_status(self, what='fused BPR-MF step'):
+        raise_on_status(self.status, what)
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation
+# ------------------------------------------------------------------------------------------------
+def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k, excl_indptr=None, excl_indices=None,
+                 item_begin=0, item_count=None, scores_ws=None, status=None):
+    """Masked score matrix of one item shard and its top-k.  -> (vals [R,k] f32, idx [R,k] i32 global, scores)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    n_users, dim = user_emb.shape
+    n_items = item_emb.shape[0]
+    if item_count is None:
+        item_count = n_items - item_begin
+    _chk(user_emb, torch.float32, 'user_emb')
+    _chk(item_emb, torch.float32, 'item_emb', (n_items, dim))
+    _chk(item_bias, torch.float32, 'item_bias', optional=True)
+    _chk(user_bias, torch.float32, 'user_bias', optional=True)
+    _chk(global_bias, torch.float32, 'global_bias', optional=True)
+    _chk(u_idx, torch.int64, 'u_idx')
+    if excl_indptr is not None:
+        _chk(excl_indptr, torch.int64, 'excl_indptr', (n_users + 1,))
+        _chk(excl_indices, torch.int32, 'excl_indices')
+    R = u_idx.numel()
+    dev = user_emb.device
+    if scores_ws is None:
+        scores_ws = torch.empty((R, item_count), dtype=torch.float32, device=dev)
+    else:
+        _chk(scores_ws, torch.float32, 'scores_ws')
+        if scores_ws.numel() < R * item_count:
+            raise ValueError('scores_ws too small')
+    vals = torch.empty((R, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((R, k), dtype=torch.int32, device=dev)
+    _lib.check(lib.hsk_mf_eval_topk(_p(user_emb), _p(item_emb), _p(item_bias), _p(user_bias), _p(global_bias),
+                                    n_users, n_items, dim, _p(u_idx), R, item_begin, item_count,
+                                    _p(excl_indptr), _p(excl_indices), k, _p(scores_ws), _p(vals), _p(idx),
+                                    _p(status), _stream()), 'hsk_mf_eval_topk')
+    return vals, idx, scores_ws
+
+
+def topk_dense(logits: torch.Tensor, k: int):
+    """(values, indices int64) of the k largest entries per row; ties broken by lower index."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(logits, torch.float32, 'logits')
+    if logits.dim() != 2:
+        raise ValueError('logits must be 2-D')
+    rows, cols = logits.shape
+    vals = torch.empty((rows, k), dtype=torch.float32, device=logits.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=logits.device)
+    _lib.check(lib.hsk_topk_dense(_p(logits), rows, cols, cols, k, _p(vals), _p(idx), _stream()), 'hsk_topk_dense')
+    return vals, idx
+
+
+def topk_merge(vals: torch.Tensor, idx: torch.Tensor):
+    """[P,R,k] candidate lists -> global top-k [R,k]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(vals, torch.float32, 'vals')
+    _chk(idx, torch.int32, 'idx', tuple(vals.shape))
+    P, R, k = vals.shape
+    ov = torch.empty((R, k), dtype=torch.float32, device=vals.device)
+    oi = torch.empty((R, k), dtype=torch.int32, device=vals.device)
+    _lib.check(lib.hsk_topk_merge(_p(vals), _p(idx), P, R, k, _p(ov), _p(oi), _stream()), 'hsk_topk_merge')
+    return ov, oi
+
+
+def rank_metrics(topk_idx: torch.Tensor, u_idx: torch.Tensor, label_indptr: torch.Tensor,
+                 label_indices: torch.Tensor, ks: Sequence[int]) -> torch.Tensor:
+    """-> [R, len(ks), 3] (precision, recall, ndcg) per user and cut-off."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(topk_idx, torch.int32, 'topk_idx')
+    _chk(u_idx, torch.int64, 'u_idx')
+    _chk(label_indptr, torch.int64, 'label_indptr')
+    _chk(label_indices, torch.int32, 'label_indices')
+    R, kmax = topk_idx.shape
+    if u_idx.shape != (R,):
+        raise ValueError('u_idx / topk_idx row mismatch')
+    ks_arr = (ctypes.c_int32 * len(ks))(*[int(x) for x in ks])
+    out = torch.empty((R, len(ks), 3), dtype=torch.float32, device=topk_idx.device)
+    _lib.check(lib.hsk_rank_metrics(_p(topk_idx), R, kmax, _p(u_idx), label_indptr.numel() - 1, _p(label_indptr),
+                                    _p(label_indices), ks_arr,
+                                    len(ks), _p(out), _stream()), 'hsk_rank_metrics')
+    return out

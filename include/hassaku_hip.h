@@ -1,0 +1,219 @@
+/*
+ * hassaku_hip.h -- C ABI of libhassaku_hip.so: the MI355X (gfx950) BPR-MF training / full-eval path.
+ *
+ * The reference (karapostK/hassaku) has no FFI of its own: the seam is a Python plugin API
+ * (SURVEY.md section 8b).  Every entry point below names the reference interface it replaces
+ * (paths relative to the reference tree).  All pointers are DEVICE pointers unless stated, all
+ * tables are dense row-major fp32 with leading dimension == dim (the nn.Embedding layout, so
+ * state_dict()/model.pth round-trip unchanged), every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*), allocates nothing and returns 0 on success.  On failure a
+ * non-zero code is returned and hsk_last_error() holds the text (thread-local).
+ *
+ * Index arrays on the drop-in surface are int64 (the dtype the reference's loader yields,
+ * data/dataloader.py:126-129).  Out-of-range indices never touch memory: they are clamped to row
+ * 0 and bit 0 of *status is set (the reference raises IndexError / device assert instead).
+ */
+#ifndef HASSAKU_HIP_H
+#define HASSAKU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hsk_stream_t; /* hipStream_t */
+
+enum {
+  HSK_OK = 0,
+  HSK_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, ...) */
+  HSK_ERR_UNSUPPORTED = 2, /* shape outside what the kernels are instantiated for */
+  HSK_ERR_HIP = 3          /* a HIP runtime call failed */
+};
+
+/* bits of the device-side status word */
+enum {
+  HSK_STATUS_BAD_INDEX = 1,       /* an index was outside [0, n) and was clamped */
+  HSK_STATUS_SAMPLER_GAVE_UP = 2  /* rejection sampler hit its retry cap (user owns ~all items) */
+};
+
+/* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
+int hsk_version(void);
+const char* hsk_last_error(void);
+/* number of CUs / wavefront size / gcn arch name of the current device (host pointers) */
+int hsk_device_info(int32_t* cu_count, int32_t* wave_size, char* arch, int32_t arch_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * Un-fused operators (drop-in for the autograd path of an unmodified Trainer.fit)
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * logits[b,k] = <user_emb[u[b]], item_emb[i[b,k]]> (+ user_bias[u[b]]) (+ item_bias[i[b,k]]) (+ global_bias)
+ * Replaces SGDBasedRecommenderAlgorithm.forward (algorithms/base_classes.py:99-108) =
+ * SGDMatrixFactorization.get_user_representations / get_item_representations /
+ * combine_user_item_representations (algorithms/sgd_alg.py:148-179).
+ * Bias pointers may be NULL (bias disabled).  u_idx: [batch], i_idx: [batch, n_cols].
+ */
+int hsk_mf_scores(const float* user_emb, const float* item_emb, const float* item_bias,
+                  const float* user_bias, const float* global_bias,
+                  int64_t n_users, int64_t n_items, int64_t dim,
+                  const int64_t* u_idx, const int64_t* i_idx, int64_t batch, int64_t n_cols,
+                  float* logits, int32_t* status, hsk_stream_t stream);
+
+/*
+ * BPR loss on logits [batch, n_cols] (column 0 = positive):
+ *   loss = mean_{b,n} softplus(-(logits[b,0] - logits[b,1+n]))   (fp64 accumulate, fp64 result)
+ * and, if grad_logits != NULL, d loss / d logits (fp32, already divided by batch*(n_cols-1)).
+ * Replaces RecBayesianPersonalizedRankingLoss.compute_loss (train/rec_losses.py:68-88) and its
+ * autograd backward.  ws: device scratch of `batch` doubles.
+ */
+int hsk_bpr_loss_grad(const float* logits, int64_t batch, int64_t n_cols,
+                      double* loss, float* grad_logits, double* ws, hsk_stream_t stream);
+
+/*
+ * Dense parameter gradients of hsk_mf_scores given grad_logits [batch, n_cols]
+ * (what autograd's embedding_dense_backward produces for train/trainer.py:146).
+ * Output buffers are fully overwritten (zero for rows not in the batch).  NULL outputs are skipped.
+ */
+int hsk_mf_backward(const float* user_emb, const float* item_emb,
+                    int64_t n_users, int64_t n_items, int64_t dim,
+                    const int64_t* u_idx, const int64_t* i_idx, int64_t batch, int64_t n_cols,
+                    const float* grad_logits,
+                    float* g_user_emb, float* g_item_emb, float* g_item_bias,
+                    float* g_user_bias, float* g_global_bias,
+                    int32_t* status, hsk_stream_t stream);
+
+/*
+ * One dense AdamW step on a flat parameter of n elements -- torch.optim.AdamW defaults
+ * (train/trainer.py:52-53,147): p*=1-lr*wd; m=lerp(m,g,1-b1); v=b2*v+(1-b2)g^2;
+ * p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  `step` is t (1-based, after increment).
+ * g == NULL means an all-zero gradient.
+ */
+int hsk_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n,
+                    double lr, double beta1, double beta2, double eps, double wd, int64_t step,
+                    hsk_stream_t stream);
+
+/*
+ * Uniform negative sampling with rejection of the user's training positives.
+ * Replaces NegativeSampler._neg_sample_uniform + TrainDataLoader._neg_sampling_collate_fn
+ * (data/dataloader.py:56-57,92-129): neg[b,n] ~ U{[0,n_items) \ csr_row(u[b])}, i.i.d. with
+ * replacement.  csr_indices must be sorted inside each row.  RNG: Philox4x32-10 keyed by `seed`,
+ * counter (stream_id, b, n, attempt) -- reproducible and independent of launch geometry.
+ */
+int hsk_sample_negatives_uniform(const int64_t* csr_indptr, const int32_t* csr_indices,
+                                 int64_t n_users, int64_t n_items,
+                                 const int64_t* u_idx, int64_t batch, int64_t n_neg,
+                                 uint64_t seed, uint64_t stream_id,
+                                 int64_t* neg_out, int32_t* status, hsk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused BPR-MF AdamW training step (the hot path of Trainer.fit, train/trainer.py:128-148)
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct hsk_bprmf_state {
+  /* parameters: user_emb [U,D], item_emb [I,D], item_bias [I], user_bias [U], global_bias [1];
+     bias pointers NULL when disabled (algorithms/sgd_alg.py:127-138) */
+  float* user_emb;
+  float* item_emb;
+  float* item_bias;
+  float* user_bias;
+  float* global_bias;
+  /* AdamW first/second moments, same shapes (torch.optim.AdamW state 'exp_avg','exp_avg_sq') */
+  float* m_user_emb;   float* v_user_emb;
+  float* m_item_emb;   float* v_item_emb;
+  float* m_item_bias;  float* v_item_bias;
+  float* m_user_bias;  float* v_user_bias;
+  float* m_global_bias; float* v_global_bias;
+  int64_t n_users, n_items, dim;
+  /* hyper-parameters (conf keys lr, wd; betas/eps = torch defaults unless overridden) */
+  double lr, beta1, beta2, eps, wd;
+  /* number of optimizer steps applied so far; hsk_bprmf_train_step* increments it (host side) */
+  int64_t step;
+  /* training interactions: CSR by user (sorted rows) for the sampler; COO for iteration */
+  const int64_t* csr_indptr;   /* [U+1] */
+  const int32_t* csr_indices;  /* [nnz] */
+  const int32_t* coo_user;     /* [nnz] */
+  const int32_t* coo_item;     /* [nnz] */
+  int64_t nnz;
+  uint64_t seed;
+  /* scratch, sized by hsk_bprmf_workspace_bytes, prepared once by hsk_bprmf_init_workspace */
+  void* workspace;
+  int64_t workspace_bytes;
+  int64_t max_batch, max_cols;
+  /* lazy user-table AdamW: 0 = dense sweep every step (reference order of operations),
+     1 = exact lazy catch-up of untouched rows (needs hsk_bprmf_flush before reading user tables) */
+  int32_t lazy_users;
+  int32_t reserved0;
+  /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
+  double* loss_out;
+  int32_t* status;
+} hsk_bprmf_state;
+
+int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim,
+                                  int64_t max_batch, int64_t max_cols);
+int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t stream);
+
+/* One step on a loader-provided batch (u_idx [batch], i_idx [batch, n_cols], column 0 positive):
+ * forward + BPR loss + backward + AdamW on every parameter, results equal to the reference's
+ * out=model(u,i); loss=bpr(out,labels); loss.backward(); optimizer.step() on the same batch. */
+int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, const int64_t* i_idx,
+                         int64_t batch, int64_t n_cols, hsk_stream_t stream);
+
+/* Same step with the batch built on the device: positives = interactions order[start .. start+batch)
+ * of the COO (order == NULL: identity), n_neg negatives each from the on-device rejection sampler. */
+int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* order, int64_t start,
+                                 int64_t batch, int64_t n_neg, hsk_stream_t stream);
+
+/* Bring lazily-updated user rows up to st->step (no-op when lazy_users == 0). */
+int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
+
+/* Copy of the device batch the last *_sampled step used (debug / parity): u [batch], items [batch,n_cols] */
+int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols,
+                         int64_t* u_out, int64_t* i_out, hsk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Full-catalogue evaluation (eval/eval.py:237-253, eval/eval.py:54-99, eval/metrics.py:4-105)
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * scores[r, j] = <user_emb[u[r]], item_emb[item_begin+j]> + biases, j in [0,item_count), fp32
+ * (exact-fp32 MFMA); entries (u[r], item) present in the exclude CSR get -inf; then the k best per
+ * row are returned sorted by (score desc, item id asc).  out_idx holds GLOBAL item ids.
+ * scores_ws: [n_rows, item_count] floats of scratch (also the masked score matrix on return).
+ * Replaces get_item_representations(arange(I)) + combine_user_item_representations + mask +
+ * logits.topk (eval/eval.py:240-251, :63) for one item shard.
+ */
+int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, const float* item_bias,
+                     const float* user_bias, const float* global_bias,
+                     int64_t n_users, int64_t n_items, int64_t dim,
+                     const int64_t* u_idx, int64_t n_rows,
+                     int64_t item_begin, int64_t item_count,
+                     const int64_t* excl_indptr, const int32_t* excl_indices,
+                     int64_t k, float* scores_ws, float* out_vals, int32_t* out_idx,
+                     int32_t* status, hsk_stream_t stream);
+
+/* top-k of each row of a dense [rows, cols] fp32 matrix (leading dimension ld); indices int64
+ * (torch.topk dtype); order (value desc, index asc).  Replaces logits.topk(k) (eval/eval.py:63). */
+int hsk_topk_dense(const float* logits, int64_t rows, int64_t cols, int64_t ld, int64_t k,
+                   float* out_vals, int64_t* out_idx, hsk_stream_t stream);
+
+/* merge n_parts candidate lists [n_parts, rows, k] (e.g. all-gathered item shards) into the global
+ * top-k per row, same ordering rule. */
+int hsk_topk_merge(const float* vals, const int32_t* idx, int64_t n_parts, int64_t rows, int64_t k,
+                   float* out_vals, int32_t* out_idx, hsk_stream_t stream);
+
+/*
+ * Per-user precision@k, recall@k, ndcg@k for each k in ks (host array, descending or any order)
+ * from a ranked list topk_idx [n_rows, k_max] and the ground-truth CSR (sorted rows) of the split:
+ * out[r, 3*t+0..2] = precision, recall, ndcg at ks[t].  Semantics of eval/metrics.py:4-105
+ * (recall and ndcg are 0 for users without ground truth; ndcg clamped to <= 1).
+ */
+int hsk_rank_metrics(const int32_t* topk_idx, int64_t n_rows, int64_t k_max,
+                     const int64_t* u_idx, int64_t n_users,
+                     const int64_t* label_indptr, const int32_t* label_indices,
+                     const int32_t* ks, int32_t n_ks, float* out, hsk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HASSAKU_HIP_H */

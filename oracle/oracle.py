@@ -1,0 +1,217 @@
+"""TEST INFRASTRUCTURE ONLY -- Python face of the CPU oracle (oracle/bprmf_oracle.c) plus the numpy
+restatement of the reference's host-side sampler.  Import from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg only; never from hassaku_amd/.
+
+Parity status: PINNED by golden vectors generated from the imported reference
+(oracle/gen_golden.py -> tests/golden/*.npz, checked in tests/test_oracle_golden.py).
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import c_double, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'liboracle.so')
+_lib = None
+
+
+def build(force: bool = False):
+    src = os.path.join(_HERE, 'bprmf_oracle.c')
+    if force or not os.path.isfile(SO_PATH) or os.path.getmtime(SO_PATH) < os.path.getmtime(src):
+        subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-fPIC', '-shared', '-o', SO_PATH, src, '-lm'])
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(SO_PATH):
+            build()
+        _lib = ctypes.CDLL(SO_PATH)
+        _lib.orc_bpr_loss_grad.restype = c_double
+        _lib.orc_count_bad_negatives.restype = c_int64
+    return _lib
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def mf_scores(U, I, Ib, Ub, gb, u_idx, i_idx):
+    """algorithms/sgd_alg.py:148-179"""
+    U, I, Ib, Ub, gb = _f32(U), _f32(I), _f32(Ib), _f32(Ub), _f32(gb)
+    u_idx, i_idx = _i64(u_idx), _i64(i_idx)
+    B, K = i_idx.shape
+    out = np.empty((B, K), dtype=np.float32)
+    lib().orc_mf_scores(_p(U), _p(I), _p(Ib), _p(Ub), _p(gb), c_int64(U.shape[1]), _p(u_idx), _p(i_idx),
+                        c_int64(B), c_int64(K), _p(out))
+    return out
+
+
+def bpr_loss_grad(logits, need_grad=True):
+    """train/rec_losses.py:68-88 (+ autograd)"""
+    logits = _f32(logits)
+    B, K = logits.shape
+    grad = np.empty_like(logits) if need_grad else None
+    loss = lib().orc_bpr_loss_grad(_p(logits), c_int64(B), c_int64(K), _p(grad))
+    return float(loss), grad
+
+
+def mf_backward(U, I, u_idx, i_idx, g, item_bias=True, user_bias=False, global_bias=False):
+    """autograd backward of mf_scores -> dense grads"""
+    U, I, g = _f32(U), _f32(I), _f32(g)
+    u_idx, i_idx = _i64(u_idx), _i64(i_idx)
+    B, K = i_idx.shape
+    gU, gI = np.empty_like(U), np.empty_like(I)
+    gIb = np.empty(I.shape[0], np.float32) if item_bias else None
+    gUb = np.empty(U.shape[0], np.float32) if user_bias else None
+    ggb = np.empty(1, np.float32) if global_bias else None
+    lib().orc_mf_backward(_p(U), _p(I), c_int64(U.shape[0]), c_int64(I.shape[0]), c_int64(U.shape[1]), _p(u_idx),
+                          _p(i_idx), c_int64(B), c_int64(K), _p(g), _p(gU), _p(gI), _p(gIb), _p(gUb), _p(ggb))
+    return gU, gI, gIb, gUb, ggb
+
+
+def adamw_step(p, g, m, v, lr, wd, step, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.AdamW single-tensor step, in place on float32 numpy arrays (g None = zeros)."""
+    for a in (p, m, v):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    g = _f32(g)
+    lib().orc_adamw_step(_p(p), _p(g), _p(m), _p(v), c_int64(p.size), c_double(lr), c_double(b1), c_double(b2),
+                         c_double(eps), c_double(wd), c_int64(step))
+
+
+class MfOracleTrainer:
+    """Dense restatement of one Trainer.fit step (train/trainer.py:128-148) for MF + BPR + AdamW.
+
+    d loss/d user_bias and d loss/d global_bias are defined as exactly 0 (they cancel in
+    s_pos - s_neg; the reference's ~1e-9 autograd noise there is amplified by Adam and is not part
+    of the contract -- SURVEY.md section 7, hard part 2)."""
+
+    def __init__(self, U, I, Ib=None, Ub=None, gb=None, lr=1e-3, wd=0.0):
+        self.P = {'user_emb': _f32(U).copy(), 'item_emb': _f32(I).copy()}
+        if Ib is not None:
+            self.P['item_bias'] = _f32(Ib).reshape(-1).copy()
+        if Ub is not None:
+            self.P['user_bias'] = _f32(Ub).reshape(-1).copy()
+        if gb is not None:
+            self.P['global_bias'] = _f32(gb).reshape(-1).copy()
+        self.M = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.V = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.lr, self.wd, self.t = lr, wd, 0
+
+    def forward(self, u_idx, i_idx):
+        P = self.P
+        return mf_scores(P['user_emb'], P['item_emb'], P.get('item_bias'), P.get('user_bias'), P.get('global_bias'),
+                         u_idx, i_idx)
+
+    def step(self, u_idx, i_idx):
+        P = self.P
+        logits = self.forward(u_idx, i_idx)
+        loss, g = bpr_loss_grad(logits)
+        gU, gI, gIb, _, _ = mf_backward(P['user_emb'], P['item_emb'], u_idx, i_idx, g, item_bias='item_bias' in P)
+        grads = {'user_emb': gU, 'item_emb': gI, 'item_bias': gIb, 'user_bias': None, 'global_bias': None}
+        self.t += 1
+        for k in P:
+            adamw_step(P[k], grads[k], self.M[k], self.V[k], self.lr, self.wd, self.t)
+        return loss, logits, g, grads
+
+
+def count_bad_negatives(indptr, indices, n_items, u_idx, neg):
+    indptr, indices, u_idx, neg = _i64(indptr), _i32(indices), _i64(u_idx), _i64(neg)
+    B, N = neg.shape
+    return int(lib().orc_count_bad_negatives(_p(indptr), _p(indices), c_int64(n_items), _p(u_idx), _p(neg),
+                                             c_int64(B), c_int64(N)))
+
+
+def sample_negatives_reference_style(rng: np.random.RandomState, indptr, indices, n_items, u_idx, n_neg):
+    """Restatement of TrainDataLoader._neg_sampling_collate_fn (data/dataloader.py:110-124): draw for all
+    open slots with randint, re-test every row against the user's CSR row, repeat until no hit."""
+    B = len(u_idx)
+    neg = np.empty((B, n_neg), dtype=np.int64)
+    open_ = np.ones((B, n_neg), dtype=bool)
+    todo = open_.sum()
+    while todo:
+        neg[open_] = rng.randint(0, high=n_items, size=todo)
+        for b in range(B):
+            u = u_idx[b]
+            open_[b] = np.isin(neg[b], indices[indptr[u]:indptr[u + 1]])
+        todo = open_.sum()
+    return neg
+
+
+def eval_scores(U, I, Ib, Ub, gb, u_idx, excl_indptr=None, excl_indices=None):
+    """eval/eval.py:240-251"""
+    U, I, Ib, Ub, gb = _f32(U), _f32(I), _f32(Ib), _f32(Ub), _f32(gb)
+    u_idx = _i64(u_idx)
+    R, n_items = len(u_idx), I.shape[0]
+    out = np.empty((R, n_items), dtype=np.float32)
+    ip = None if excl_indptr is None else _i64(excl_indptr)
+    ii = None if excl_indices is None else _i32(excl_indices)
+    lib().orc_eval_scores(_p(U), _p(I), _p(Ib), _p(Ub), _p(gb), c_int64(n_items), c_int64(U.shape[1]), _p(u_idx),
+                          c_int64(R), _p(ip), _p(ii), _p(out))
+    return out
+
+
+def topk(x, k):
+    """logits.topk(k): values desc, ties by lower index"""
+    x = _f32(x)
+    R, C = x.shape
+    vals = np.empty((R, k), np.float32)
+    idx = np.empty((R, k), np.int64)
+    lib().orc_topk(_p(x), c_int64(R), c_int64(C), c_int64(k), _p(vals), _p(idx))
+    return vals, idx
+
+
+def rank_metrics(topk_idx, u_idx, indptr, indices, ks):
+    """eval/metrics.py:4-105 -> [R, len(ks), 3] (precision, recall, ndcg)"""
+    topk_idx, u_idx, indptr, indices = _i64(topk_idx), _i64(u_idx), _i64(indptr), _i32(indices)
+    ks_a = _i32(ks)
+    R, kmax = topk_idx.shape
+    out = np.empty((R, len(ks), 3), np.float32)
+    lib().orc_rank_metrics(_p(topk_idx), c_int64(R), c_int64(kmax), _p(u_idx), _p(indptr), _p(indices), _p(ks_a),
+                           c_int32(len(ks)), _p(out))
+    return out
+
+
+def full_eval_metrics(U, I, Ib, Ub, gb, u_all, excl_indptr, excl_indices, lab_indptr, lab_indices,
+                      ks=(5, 10, 50, 100), user_group=None, n_groups=0, batch=256):
+    """evaluate_recommender_algorithm + FullEvaluator (eval/eval.py:54-118,237-255): mean metrics over
+    users, plus `group_<g>_` variants."""
+    kmax = max(ks)
+    sums = {}
+    counts = {-1: 0}
+    for lo in range(0, len(u_all), batch):
+        ub = np.asarray(u_all[lo:lo + batch], dtype=np.int64)
+        sc = eval_scores(U, I, Ib, Ub, gb, ub, excl_indptr, excl_indices)
+        _, ids = topk(sc, kmax)
+        met = rank_metrics(ids, ub, lab_indptr, lab_indices, ks)
+        counts[-1] += len(ub)
+        groups = [(-1, np.ones(len(ub), bool))]
+        if n_groups > 0:
+            for g in range(n_groups):
+                sel = np.asarray(user_group)[ub] == g
+                counts[g] = counts.get(g, 0) + int(sel.sum())
+                groups.append((g, sel))
+        for g, sel in groups:
+            for t, k in enumerate(ks):
+                for j, name in enumerate(('precision', 'recall', 'ndcg')):
+                    key = (g, f'{name}@{k}')
+                    sums[key] = sums.get(key, 0.0) + float(met[sel, t, j].astype(np.float64).sum())
+    out = {}
+    for (g, name), s in sums.items():
+        out[name if g == -1 else f'group_{g}_{name}'] = s / counts[g]
+    return out

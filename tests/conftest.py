@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) when no device is visible, e.g. in the authoring container
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason='no HIP device visible')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def csr_from_pairs(pairs, n_rows):
+    """(indptr int64 [n_rows+1], indices int32 sorted+deduplicated per row) from [n,2] (row, col) pairs."""
+    pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    key = np.unique(pairs[:, 0] * (1 << 32) + pairs[:, 1])
+    rows, cols = key >> 32, key & 0xffffffff
+    indptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(indptr, rows + 1, 1)
+    return np.cumsum(indptr), cols.astype(np.int32)
+
+
+def max_norm_err(a, b):
+    """max |a-b| / max |b| -- the tensor-max-normalised error used for Adam-updated tensors."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.abs(b).max()
+    return float(np.abs(a - b).max() / (den if den > 0 else 1.0))
+
+
+G1_CASES = ['d16_item', 'd64_item', 'd402_item', 'd64_all', 'd30_none', 'd64_dups']
+PARAM_KEYS = {  # state_dict key -> short name used by the oracle / fused state
+    'user_embeddings.weight': 'user_emb', 'item_embeddings.weight': 'item_emb',
+    'item_bias.weight': 'item_bias', 'user_bias.weight': 'user_bias', 'global_bias': 'global_bias'}
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
