@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR triplets/s of the fused MI355X BPR-MF training step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ml10m|ml1m|ml100k]
+
+One "step" = one full training step of Trainer.fit on one batch of synthetic interactions: on-device
+uniform rejection sampling of the negatives, embedding gathers, (u.i - u.j) scores with item bias,
+BPR log-sigmoid loss, gradients, and the AdamW update of every parameter row (dense semantics of
+torch.optim.AdamW).  Inputs (tables, interaction CSR/COO, the epoch permutation) are resident in HBM
+before the timed region.  Default workload: BASELINE.json configs[2] (ml10m shape, D=512, N=100,
+B=4096) -- the configuration the metric "% HBM-read roofline at dim=512" is quoted on.
+
+Rank 0 prints ONE JSON line (see the driver contract).  `roofline` describes the gather+BPR kernel
+(k_fwd_ugrad): algorithmic read bytes per launch / its mean duration, measured with HIP events on
+the launch stream inside the timed region.  `cpu_baseline` times the CPU restatement of the
+reference's trainer (oracle/cpu_trainer.py, kind "port") on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # name: (synthetic shape, D, n_neg, batch)  -- BASELINE.json configs[0..2]
+    'ml100k': ('ml100k', 64, 1, 128),
+    'ml1m': ('ml1m', 402, 50, 128),
+    'ml10m': ('ml10m', 512, 100, 4096),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LR, WD = 3e-4, 4e-5    # README.md:82-83 of the reference (canonical BPR-MF conf)
+
+
+def fwd_read_bytes(B, N, D):
+    """Algorithmic HBM read bytes of one k_fwd_ugrad launch (negatives read from memory):
+    user rows + (1+N) item rows per positive, item bias, item ids, user ids."""
+    return 4 * D * B * (2 + N) + 4 * B * (1 + N) + 4 * B * (1 + N) + 4 * B
+
+
+def build_state(data, D, B, N, device, seed=64):
+    from hassaku_amd import hip_ops as ops
+    from hassaku_amd.data.csr import UserItemCsr
+    U, I = data.n_users, data.n_items
+    csr = UserItemCsr.from_pairs(data.train[:, 0], data.train[:, 1], U, I)
+    torch.manual_seed(seed)
+    user_emb = torch.empty((U, D), device=device).normal_(std=0.1 / D)   # train/utils.py:12-13 of the reference
+    item_emb = torch.empty((I, D), device=device).normal_(std=0.1 / D)
+    item_bias = torch.empty((I,), device=device).normal_(std=0.1)        # [I,1] table: std 0.1/1
+    indptr, indices = csr.to_device(device)
+    coo_u = torch.from_numpy(data.train[:, 0].astype(np.int32)).to(device)
+    coo_i = torch.from_numpy(data.train[:, 1].astype(np.int32)).to(device)
+    st = ops.BprMfFusedState(user_emb, item_emb, item_bias, lr=LR, wd=WD, max_batch=B, max_cols=N + 1, seed=seed,
+                             csr_indptr=indptr, csr_indices=indices, coo_user=coo_u, coo_item=coo_i)
+    return st, csr
+
+
+def usable_cores():
+    """CPU share of this process: affinity mask, capped by the cgroup quota (a GPU box hands out 16 of its cores)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    if n > 64:      # no quota visible: stay within the documented per-GPU share
+        n = 16
+    return n
+
+
+def cpu_baseline(data, csr, D, N, B, budget_s):
+    from oracle.cpu_trainer import CpuTrainer
+    cores = usable_cores()
+    tr = CpuTrainer(data.n_users, data.n_items, D, LR, WD, csr.indptr, csr.indices, data.train[:, 0], data.train[:, 1],
+                    N, B, threads=cores)
+    steps, secs = tr.time_steps(budget_s=budget_s)
+    return {'value': steps * B * N / secs, 'unit': 'triplets/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{steps} steps of B={B} x N={N} (D={D}) in {secs:.1f}s, torch CPU + numpy sampler, 0 workers'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='ml10m', choices=sorted(WORKLOADS))
+    ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU-baseline work (0 = skip)')
+    ap.add_argument('--time-all-stages', action='store_true', help='event-time every stage (perturbs the step time)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from hassaku_amd.data import synthetic
+    shape, D, N, B = WORKLOADS[args.workload]
+    data = synthetic.generate_named(shape, seed=0)
+    st, csr = build_state(data, D, B, N, device)
+    nnz = data.train.shape[0]
+    if world > 1:
+        raise SystemExit('multi-GPU bench: not wired in this build')
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(64)
+    order = torch.randperm(nnz, device=device, generator=gen)
+    n_batches = nnz // B
+
+    def run(n, first):
+        for s in range(n):
+            st.step_sampled(order, ((first + s) % n_batches) * B, B, N)
+
+    run(args.warmup, 0)
+    torch.cuda.synchronize()
+    st.check_status('warm-up')
+    st.enable_timing(st.STAGES if args.time_all_stages else ('fwd',))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    st.disable_timing()
+    elapsed = t1 - t0
+    timing = st.collect_timing()
+    st.check_status('timed region')
+    loss = st.last_loss()
+    assert np.isfinite(loss), loss
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = args.steps * B * N * world / elapsed
+    fwd_ms, fwd_n = timing['fwd']
+    fwd_us = fwd_ms * 1e3 / fwd_n
+    achieved = fwd_read_bytes(B, N, D) / (fwd_us * 1e-6) / 1e9
+    out = {
+        'metric': 'BPR triplets/sec', 'value': value, 'unit': 'triplets/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{args.workload}-shaped synthetic, mf + bpr + adamw, embedding_dim={D}, '
+                               f'neg_train={N}, batch={B}, U={data.n_users}, I={data.n_items}, nnz_train={nnz}',
+                   'global_batch': B * world, 'parallelism': f'dp{world}', 'lr': LR, 'wd': WD,
+                   'loss_last_step': loss},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_fwd_ugrad (gather + scores + BPR + user-row grad)',
+                     'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': None, 'avg_us': fwd_us, 'launches': fwd_n,
+                     'algorithmic_bytes_per_launch': fwd_read_bytes(B, N, D)},
+    }
+    if args.time_all_stages:
+        out['stage_us'] = {k: v[0] * 1e3 / v[1] for k, v in timing.items()}
+    if rank == 0 and world == 1 and args.cpu_budget > 0:
+        out['cpu_baseline'] = cpu_baseline(data, csr, D, N, B, args.cpu_budget)
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

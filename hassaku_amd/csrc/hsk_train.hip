@@ -668,6 +668,73 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   return HSK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// per-stage HIP-event timing (host-side recorder; events are recorded on the kernels' own stream)
+// ---------------------------------------------------------------------------------------------
+#include <vector>
+struct hsk_timing {
+  std::vector<hipEvent_t> beg[HSK_STAGE_COUNT], end[HSK_STAGE_COUNT];
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+
+extern "C" void* hsk_timing_create(void) { return new hsk_timing(); }
+
+extern "C" void hsk_timing_destroy(void* t_) {
+  hsk_timing* t = (hsk_timing*)t_;
+  if (!t) return;
+  for (int s = 0; s < HSK_STAGE_COUNT; ++s) {
+    for (hipEvent_t e : t->beg[s]) (void)hipEventDestroy(e);
+    for (hipEvent_t e : t->end[s]) (void)hipEventDestroy(e);
+  }
+  for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
+  delete t;
+}
+
+extern "C" int hsk_timing_collect(void* t_, double* ms_sum, int64_t* count) {
+  hsk_timing* t = (hsk_timing*)t_;
+  HSK_REQUIRE(t && ms_sum && count, HSK_ERR_INVALID, "NULL argument");
+  for (int s = 0; s < HSK_STAGE_COUNT; ++s) {
+    for (size_t i = 0; i < t->end[s].size(); ++i) {
+      HSK_HIP(hipEventSynchronize(t->end[s][i]));
+      float ms = 0.f;
+      HSK_HIP(hipEventElapsedTime(&ms, t->beg[s][i], t->end[s][i]));
+      ms_sum[s] += (double)ms;
+      count[s] += 1;
+      t->pool.push_back(t->beg[s][i]);
+      t->pool.push_back(t->end[s][i]);
+    }
+    t->beg[s].clear();
+    t->end[s].clear();
+  }
+  return HSK_OK;
+}
+
+static inline void hsk_stage_mark(const hsk_bprmf_state* st, int stage, bool begin, hipStream_t stream) {
+  hsk_timing* t = (hsk_timing*)st->timing;
+  if (!t || !((st->timing_mask >> stage) & 1)) return;
+  hipEvent_t e = t->get();
+  if (!e) return;
+  (void)hipEventRecord(e, stream);
+  (begin ? t->beg[stage] : t->end[stage]).push_back(e);
+}
+
+#define HSK_STAGE(stage, ...)                      \
+  do {                                             \
+    hsk_stage_mark(st, (stage), true, stream);     \
+    __VA_ARGS__;                                   \
+    hsk_stage_mark(st, (stage), false, stream);    \
+  } while (0)
+
 // stages shared by the external-batch and device-sampled steps (after P0 filled u32/it32/counts/owner/cnt)
 static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t K, hipStream_t stream) {
   const int64_t total = B * K;
@@ -677,9 +744,10 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
   const double inv_bn_d = 1.0 / ((double)B * (double)(K - 1));
   const float inv_bn = (float)inv_bn_d;
 
-  k_scan_counts<<<1, 1024, 0, stream>>>(w.counts, I, w.offsets, w.cursor);
+  HSK_STAGE(HSK_STAGE_SCAN, k_scan_counts<<<1, 1024, 0, stream>>>(w.counts, I, w.offsets, w.cursor));
   HSK_LAUNCH_CHECK();
-  k_scatter_perm<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(w.it32, total, w.cursor, w.perm);
+  HSK_STAGE(HSK_STAGE_SCATTER,
+            k_scatter_perm<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(w.it32, total, w.cursor, w.perm));
   HSK_LAUNCH_CHECK();
 
   int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
@@ -687,20 +755,23 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
     constexpr int NCH = decltype(n_)::value;
     constexpr bool FULL = decltype(f_)::value;
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
-    k_fwd_ugrad<V, NCH, FULL, R><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
-        st->user_emb, st->item_emb, st->item_bias, w.u32, w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b);
-    k_item_update<V, NCH, FULL, R, true><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
-        st->user_emb, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,
-        w.u32, w.g_s, w.perm, w.offsets, w.counts, I, (int)K, D, c, nullptr, nullptr);
-    k_user_update<V, NCH, FULL, 0><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
-        st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias, st->v_user_bias, w.dUb, w.u32,
-        w.owner, w.cnt, U, (int)B, D, c, nullptr, nullptr);
+    HSK_STAGE(HSK_STAGE_FWD, (k_fwd_ugrad<V, NCH, FULL, R><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
+                                 st->user_emb, st->item_emb, st->item_bias, w.u32, w.it32, (int)B, (int)K, D, inv_bn,
+                                 w.g_s, w.dUb, w.loss_b)));
+    HSK_STAGE(HSK_STAGE_ITEM, (k_item_update<V, NCH, FULL, R, true><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
+                                  st->user_emb, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb,
+                                  st->m_item_bias, st->v_item_bias, w.u32, w.g_s, w.perm, w.offsets, w.counts, I, (int)K,
+                                  D, c, nullptr, nullptr)));
+    HSK_STAGE(HSK_STAGE_USER, (k_user_update<V, NCH, FULL, 0><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
+                                  st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
+                                  st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, U, (int)B, D, c, nullptr, nullptr)));
     return HSK_OK;
   });
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
-  k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out, st->global_bias, st->m_global_bias,
-                                        st->v_global_bias, c);
+  HSK_STAGE(HSK_STAGE_FINISH, k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out,
+                                                                     st->global_bias, st->m_global_bias,
+                                                                     st->v_global_bias, c));
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
@@ -717,9 +788,9 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   hipStream_t stream = (hipStream_t)stream_;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   const int64_t total = batch * n_cols;
-  k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
-      u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, w.u32, w.it32, w.counts, w.owner,
-      w.cnt, st->status);
+  HSK_STAGE(HSK_STAGE_PREP, k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
+                                u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, w.u32,
+                                w.it32, w.counts, w.owner, w.cnt, st->status));
   HSK_LAUNCH_CHECK();
   return hsk_run_step(st, w, batch, n_cols, stream);
 }
@@ -739,9 +810,10 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   hipStream_t stream = (hipStream_t)stream_;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   // the RNG stream id is the index of the step about to be taken: every step draws fresh negatives
-  k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
-      st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr, st->csr_indices,
-      (int)st->n_items, st->seed, (uint64_t)st->step, w.u32, w.it32, w.counts, w.owner, w.cnt, st->status);
+  HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
+                                st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
+                                st->csr_indices, (int)st->n_items, st->seed, (uint64_t)st->step, w.u32, w.it32,
+                                w.counts, w.owner, w.cnt, st->status));
   HSK_LAUNCH_CHECK();
   return hsk_run_step(st, w, batch, n_neg + 1, stream);
 }

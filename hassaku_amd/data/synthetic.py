@@ -75,8 +75,41 @@ def generate(n_users: int, n_items: int, n_interactions: int, seed: int = 0, n_g
                                  np.concatenate(va).astype(np.int64), np.concatenate(te).astype(np.int64), group)
 
 
-def generate_named(name: str, seed: int = 0, n_groups: int = 0) -> SyntheticInteractions:
+def generate_fast(n_users: int, n_items: int, n_interactions: int, seed: int = 0,
+                  min_per_user: int = 10) -> SyntheticInteractions:
+    """Vectorised variant for the large bench shapes: items are drawn WITH replacement from the same
+    Zipf-like popularity and duplicates are dropped, so users end up with slightly fewer interactions
+    than drawn.  Same split rule.  ~2 s for the ml10m shape (8 M interactions)."""
+    rng = np.random.default_rng(seed)
+    pop = np.arange(1, n_items + 1, dtype=np.float64) ** -0.8
+    pop = pop[rng.permutation(n_items)]
+    cdf = np.cumsum(pop / pop.sum())
+    counts = rng.poisson(n_interactions / n_users, size=n_users)
+    counts = np.clip(counts, min_per_user, max(min_per_user, n_items // 2)).astype(np.int64)
+    users = np.repeat(np.arange(n_users, dtype=np.int64), counts)
+    items = np.minimum(np.searchsorted(cdf, rng.random(len(users))), n_items - 1).astype(np.int64)
+    key = np.unique(users * n_items + items)          # drop duplicates; sorted by (user, item)
+    key = key[rng.permutation(len(key))]              # random "temporal" order ...
+    key = key[np.argsort(key // n_items, kind='stable')]  # ... inside each user
+    users, items = key // n_items, key % n_items
+    n_u = np.bincount(users, minlength=n_users)
+    start = np.concatenate([[0], np.cumsum(n_u)[:-1]])
+    pos = np.arange(len(users)) - start[users]
+    n_hold = np.ceil(n_u * 0.1).astype(np.int64)      # n_val = n_test = ceil(.1 n)
+    n_train = n_u - 2 * n_hold
+    is_train = pos < n_train[users]
+    is_val = (~is_train) & (pos < (n_train + n_hold)[users])
+    is_test = pos >= (n_u - n_hold)[users]
+    pairs = np.stack([users, items], 1)
+    return SyntheticInteractions(n_users, n_items, pairs[is_train], pairs[is_val], pairs[is_test], None)
+
+
+def generate_named(name: str, seed: int = 0, n_groups: int = 0, fast: Optional[bool] = None) -> SyntheticInteractions:
     u, i, n = SHAPES[name]
+    if fast is None:
+        fast = n > 1_000_000
+    if fast:
+        return generate_fast(u, i, n, seed=seed)
     return generate(u, i, n, seed=seed, n_groups=n_groups)
 
 

@@ -214,6 +214,9 @@ class BprMfFusedState:
         st.workspace, st.workspace_bytes = _p(self.workspace), nbytes
         st.max_batch, st.max_cols = self.max_batch, self.max_cols
         st.lazy_users = 0
+        st.timing_mask = 0
+        st.timing = None
+        self._timing = None
         st.loss_out, st.status = _p(self.loss_out), _p(self.status)
         self.st = st
         _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(st), _stream()), 'hsk_bprmf_init_workspace')
@@ -247,6 +250,40 @@ class BprMfFusedState:
         _lib.check(self.lib.hsk_bprmf_last_batch(ctypes.byref(self.st), batch, n_cols, _p(u), _p(i), _stream()),
                    'hsk_bprmf_last_batch')
         return u, i
+
+    STAGES = ('prep', 'scan', 'scatter', 'fwd', 'item', 'user', 'finish')
+
+    def enable_timing(self, stages=('fwd',)):
+        """Bracket the named stages of every following step with HIP events on the launch stream."""
+        if not getattr(self, '_timing', None):
+            self._timing = self.lib.hsk_timing_create()
+        mask = 0
+        for s in stages:
+            mask |= 1 << self.STAGES.index(s)
+        self.st.timing = self._timing
+        self.st.timing_mask = mask
+
+    def disable_timing(self):
+        self.st.timing_mask = 0
+
+    def collect_timing(self):
+        """-> {stage: (total_ms, n_samples)}; waits for the recorded events."""
+        if not getattr(self, '_timing', None):
+            return {}
+        n = len(self.STAGES)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int64 * n)()
+        _lib.check(self.lib.hsk_timing_collect(self._timing, ms, cnt), 'hsk_timing_collect')
+        return {s: (ms[i], cnt[i]) for i, s in enumerate(self.STAGES) if cnt[i] > 0}
+
+    def __del__(self):
+        t = getattr(self, '_timing', None)
+        if t:
+            try:
+                self.lib.hsk_timing_destroy(t)
+            except Exception:
+                pass
+            self._timing = None
 
     def flush(self):
         _lib.check(self.lib.hsk_bprmf_flush(ctypes.byref(self.st), _stream()), 'hsk_bprmf_flush')

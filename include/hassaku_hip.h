@@ -143,7 +143,10 @@ typedef struct hsk_bprmf_state {
   /* lazy user-table AdamW: 0 = dense sweep every step (reference order of operations),
      1 = exact lazy catch-up of untouched rows (needs hsk_bprmf_flush before reading user tables) */
   int32_t lazy_users;
-  int32_t reserved0;
+  /* bit s set: bracket stage s of the step with HIP events (see HSK_STAGE_*, hsk_timing_*) */
+  int32_t timing_mask;
+  /* opaque handle from hsk_timing_create, or NULL (no timing) */
+  void* timing;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;
@@ -163,6 +166,27 @@ int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, const int64_
  * of the COO (order == NULL: identity), n_neg negatives each from the on-device rejection sampler. */
 int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* order, int64_t start,
                                  int64_t batch, int64_t n_neg, hsk_stream_t stream);
+
+/* Stages of one fused step, in launch order (timing slots). */
+enum {
+  HSK_STAGE_PREP = 0,      /* batch -> int32 copies / device sampler, histogram, owner map */
+  HSK_STAGE_SCAN = 1,      /* exclusive scan of the item histogram */
+  HSK_STAGE_SCATTER = 2,   /* item-major permutation */
+  HSK_STAGE_FWD = 3,       /* gather + scores + BPR + user-row gradient (the roofline kernel) */
+  HSK_STAGE_ITEM = 4,      /* item-major gradient reduction + AdamW on item rows */
+  HSK_STAGE_USER = 5,      /* user-table AdamW */
+  HSK_STAGE_FINISH = 6,    /* loss reduction, global bias */
+  HSK_STAGE_COUNT = 7
+};
+
+/* Per-stage device timing with HIP events recorded on the stream the kernels are launched on.
+ * hsk_timing_create/destroy/collect are host-synchronous helpers and must not be called while the
+ * stream is being captured.  collect() waits for the recorded events, adds the elapsed
+ * milliseconds and the number of samples of every stage into ms_sum[HSK_STAGE_COUNT] /
+ * count[HSK_STAGE_COUNT] (host arrays), and resets the recorder. */
+void* hsk_timing_create(void);
+void hsk_timing_destroy(void* timing);
+int hsk_timing_collect(void* timing, double* ms_sum, int64_t* count);
 
 /* Bring lazily-updated user rows up to st->step (no-op when lazy_users == 0). */
 int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);

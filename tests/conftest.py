@@ -51,6 +51,24 @@ def max_norm_err(a, b):
     return float(np.abs(a - b).max() / (den if den > 0 else 1.0))
 
 
+# Adam divides by sqrt(v)+eps.  Where a gradient element is <~ eps (1e-8) by cancellation, a last-bit
+# difference of its fp32 SUM (summation order: torch sequential, oracle sequential, GPU wave tree) moves the
+# parameter by up to ~lr*dg/eps.  exp_avg / exp_avg_sq are linear / quadratic in g and carry no such
+# amplification, so they are held to 1e-5; the parameter itself is held to 1e-5 on all but a sliver of
+# elements and to ADAM_MAX_TOL on the worst one.
+ADAM_MAX_TOL = 2e-4
+ADAM_FRAC = 5e-3
+
+
+def assert_adam_param_close(got, ref, what=''):
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref) / (scale if scale > 0 else 1.0)
+    assert err.max() < ADAM_MAX_TOL, (what, 'max', err.max())
+    assert (err > 1e-5).mean() <= ADAM_FRAC, (what, 'fraction beyond 1e-5', (err > 1e-5).mean())
+
+
 G1_CASES = ['d16_item', 'd64_item', 'd402_item', 'd64_all', 'd30_none', 'd64_dups']
 PARAM_KEYS = {  # state_dict key -> short name used by the oracle / fused state
     'user_embeddings.weight': 'user_emb', 'item_embeddings.weight': 'item_emb',

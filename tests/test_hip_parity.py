@@ -1,0 +1,419 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import G1_CASES, PARAM_KEYS, assert_adam_param_close, csr_from_pairs, load_golden, max_norm_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # north_star tolerance: 1e-5 relative fp32
+
+
+def dev(a, dtype=None):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _init(fx):
+    return {name: fx['init.' + sk] for sk, name in PARAM_KEYS.items() if 'init.' + sk in fx}
+
+
+def _flat(a):
+    return None if a is None else a.reshape(-1)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from hassaku_amd import hip_ops
+    return hip_ops
+
+
+def test_library_reports_gfx950(ops):
+    import ctypes
+    from hassaku_amd import _lib
+    lib = _lib.load()
+    cu, wave = ctypes.c_int32(), ctypes.c_int32()
+    arch = ctypes.create_string_buffer(64)
+    _lib.check(lib.hsk_device_info(ctypes.byref(cu), ctypes.byref(wave), arch, 64))
+    assert wave.value == 64
+    assert arch.value.decode().startswith('gfx950'), arch.value
+
+
+@pytest.mark.parametrize('case', G1_CASES)
+def test_scores_loss_backward_vs_golden(ops, oracle, case):
+    fx = load_golden(f'g1_step_{case}.npz')
+    P = _init(fx)
+    u, i = dev(fx['s1.u_idx']), dev(fx['s1.i_idx'])
+    U, I = dev(P['user_emb']), dev(P['item_emb'])
+    Ib, Ub, gb = dev(_flat(P.get('item_bias'))), dev(_flat(P.get('user_bias'))), dev(_flat(P.get('global_bias')))
+    status = ops.new_status(U.device)
+    logits = ops.mf_scores(U, I, Ib, Ub, gb, u, i, status)
+    np.testing.assert_allclose(logits.cpu().numpy(), fx['s1.logits'], rtol=RTOL, atol=1e-9)
+    loss, g = ops.bpr_loss_grad(dev(fx['s1.logits']))
+    assert abs(loss.item() - float(fx['s1.loss'])) <= 1e-6 * float(fx['s1.loss'])
+    np.testing.assert_allclose(g.cpu().numpy(), fx['s1.grad_logits'], rtol=RTOL, atol=1e-12)
+    gU, gI, gIb, gUb, ggb = ops.mf_backward(U, I, u, i, dev(fx['s1.grad_logits']), True, True, True, status)
+    assert max_norm_err(gU.cpu().numpy(), fx['s1.grad.user_embeddings.weight']) < RTOL
+    assert max_norm_err(gI.cpu().numpy(), fx['s1.grad.item_embeddings.weight']) < RTOL
+    if 'item_bias' in P:
+        assert max_norm_err(gIb.cpu().numpy(), fx['s1.grad.item_bias.weight'].reshape(-1)) < RTOL
+    ops.raise_on_status(status)
+
+
+@pytest.mark.parametrize('case', G1_CASES)
+def test_adamw_dense_on_reference_grads(ops, case):
+    fx = load_golden(f'g1_step_{case}.npz')
+    for sk in PARAM_KEYS:
+        if 'init.' + sk not in fx:
+            continue
+        p = dev(fx['init.' + sk])
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        ops.adamw_dense(p, dev(fx['s1.grad.' + sk]), m, v, float(fx['lr']), float(fx['wd']), 1)
+        assert max_norm_err(p.cpu().numpy(), fx['s1.param.' + sk]) < 1e-6, sk
+        assert max_norm_err(m.cpu().numpy(), fx['s1.m.' + sk]) < 1e-6, sk
+        assert max_norm_err(v.cpu().numpy(), fx['s1.v.' + sk]) < 1e-6, sk
+
+
+def _fused_state(ops, P, lr, wd, max_batch, max_cols, **kw):
+    t = {k: dev(_flat(v)) if k != 'user_emb' and k != 'item_emb' else dev(v) for k, v in P.items()}
+    st = ops.BprMfFusedState(t['user_emb'], t['item_emb'], t.get('item_bias'), t.get('user_bias'), t.get('global_bias'),
+                             lr=lr, wd=wd, max_batch=max_batch, max_cols=max_cols, **kw)
+    return st, t
+
+
+@pytest.mark.parametrize('case', G1_CASES)
+def test_fused_step_three_steps_vs_golden(ops, case):
+    """hsk_bprmf_train_step on the reference's own batches: loss, parameters, exp_avg, exp_avg_sq."""
+    fx = load_golden(f'g1_step_{case}.npz')
+    P = _init(fx)
+    B, K = fx['s1.i_idx'].shape
+    st, t = _fused_state(ops, P, float(fx['lr']), float(fx['wd']), B, K)
+    for step in (1, 2, 3):
+        st.step(dev(fx[f's{step}.u_idx']), dev(fx[f's{step}.i_idx']))
+        loss = st.last_loss()
+        assert abs(loss - float(fx[f's{step}.loss'])) <= 1e-6 * float(fx[f's{step}.loss']), step
+        if step in (1, 3):
+            for sk, name in PARAM_KEYS.items():
+                if name in ('user_bias', 'global_bias') or name not in P:
+                    continue
+                ref = fx[f's{step}.param.{sk}'].reshape(-1)
+                assert_adam_param_close(t[name].cpu().numpy().reshape(-1), ref, (step, name))
+                m_got, v_got = st.m[name].cpu().numpy().reshape(-1), st.v[name].cpu().numpy().reshape(-1)
+                m_ref, v_ref = fx[f's{step}.m.{sk}'].reshape(-1), fx[f's{step}.v.{sk}'].reshape(-1)
+                if step == 1:   # linear / quadratic in the step-1 gradient: no Adam amplification yet
+                    assert max_norm_err(m_got, m_ref) < RTOL and max_norm_err(v_got, v_ref) < RTOL, name
+                else:           # later gradients are taken at parameters that already carry it
+                    assert_adam_param_close(m_got, m_ref, (step, 'm', name))
+                    assert_adam_param_close(v_got, v_ref, (step, 'v', name))
+    st.check_status()
+    assert st.step_count == 3
+
+
+def test_fused_step_zero_grad_biases_only_decay(ops):
+    """user_bias / global_bias have exactly-zero BPR gradients: AdamW leaves only the weight decay."""
+    fx = load_golden('g1_step_d64_all.npz')
+    P = _init(fx)
+    B, K = fx['s1.i_idx'].shape
+    lr, wd = float(fx['lr']), float(fx['wd'])
+    st, t = _fused_state(ops, P, lr, wd, B, K)
+    for step in (1, 2, 3):
+        st.step(dev(fx[f's{step}.u_idx']), dev(fx[f's{step}.i_idx']))
+    d = np.float32(1.0 - lr * wd)
+    exp_ub = P['user_bias'].reshape(-1) * d * d * d
+    np.testing.assert_allclose(t['user_bias'].cpu().numpy(), exp_ub, rtol=1e-6)
+    assert float(st.m['user_bias'].abs().max()) == 0.0 and float(st.v['global_bias'].abs().max()) == 0.0
+
+
+def test_fused_replay_of_reference_fit(ops, oracle):
+    """G4: the exact batch stream of a 2-epoch reference Trainer.fit (ragged last batches included)."""
+    fx = load_golden('g4_fit.npz')
+    P = {'user_emb': fx['init.user_embeddings.weight'], 'item_emb': fx['init.item_embeddings.weight'],
+         'item_bias': fx['init.item_bias.weight']}
+    K = int(fx['n_neg']) + 1
+    st, t = _fused_state(ops, P, float(fx['lr']), float(fx['wd']), int(fx['batch_size']), K)
+    tr = oracle.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], lr=float(fx['lr']), wd=float(fx['wd']))
+    spe = int(fx['steps_per_epoch'])
+    for s in range(int(fx['n_steps'])):
+        u, i = fx[f'b{s}.u'], fx[f'b{s}.i']
+        st.step(dev(u), dev(i))
+        loss_ref, _, _, _ = tr.step(u, i)
+        if s % 7 == 0:
+            assert abs(st.last_loss() - loss_ref) <= 1e-6 * loss_ref
+        if s == spe - 1:
+            ep_loss = st.pop_loss_sum() / spe
+            assert 0.6 < ep_loss < 0.7
+    assert_adam_param_close(t['user_emb'].cpu().numpy(), fx['final.user_embeddings.weight'], '')
+    assert_adam_param_close(t['item_emb'].cpu().numpy(), fx['final.item_embeddings.weight'], '')
+    assert_adam_param_close(t['item_bias'].cpu().numpy(), fx['final.item_bias.weight'].reshape(-1), '')
+    assert_adam_param_close(t['user_emb'].cpu().numpy(), tr.P['user_emb'], '')
+    st.check_status()
+
+
+@pytest.mark.parametrize('D,U,I,B,N', [(512, 300, 500, 256, 100), (402, 200, 333, 128, 50), (64, 100, 150, 128, 1),
+                                        (1024, 64, 200, 32, 200), (33, 50, 101, 17, 3), (6, 20, 100, 5, 130)])
+def test_fused_step_vs_oracle_random_shapes(ops, oracle, D, U, I, B, N):
+    """BASELINE config shapes (D=512/N=100, D=402/N=50, D=64/N=1, D=1024/N=200) and odd sizes, 2 steps."""
+    rng = np.random.RandomState(D + B)
+    P = {'user_emb': (rng.randn(U, D) * 0.1).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.1).astype(np.float32),
+         'item_bias': (rng.randn(I) * 0.1).astype(np.float32)}
+    lr, wd = 3e-4, 4e-5
+    st, t = _fused_state(ops, P, lr, wd, B, N + 1)
+    tr = oracle.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], lr=lr, wd=wd)
+    for step in range(2):
+        u = rng.randint(0, U, size=B).astype(np.int64)
+        i = rng.randint(0, I, size=(B, N + 1)).astype(np.int64)
+        st.step(dev(u), dev(i))
+        loss_ref, _, _, _ = tr.step(u, i)
+        assert abs(st.last_loss() - loss_ref) <= 1e-6 * loss_ref
+    for name in P:
+        assert_adam_param_close(st.m[name].cpu().numpy(), tr.M[name], ('m', name))
+        assert_adam_param_close(st.v[name].cpu().numpy(), tr.V[name], ('v', name))
+        assert_adam_param_close(t[name].cpu().numpy(), tr.P[name], name)
+    st.check_status()
+
+
+def test_bad_index_is_flagged_not_fatal(ops):
+    U = torch.randn(10, 16, device='cuda')
+    I = torch.randn(12, 16, device='cuda')
+    status = ops.new_status(U.device)
+    u = torch.tensor([0, 3], device='cuda')
+    i = torch.tensor([[1, 2], [5, 99]], device='cuda')
+    ops.mf_scores(U, I, None, None, None, u, i, status)
+    with pytest.raises(IndexError):
+        ops.raise_on_status(status)
+
+
+def test_cpu_tensors_are_refused(ops):
+    with pytest.raises(RuntimeError):
+        ops.mf_scores(torch.randn(4, 8), torch.randn(4, 8), None, None, None, torch.zeros(1, dtype=torch.int64),
+                      torch.zeros((1, 2), dtype=torch.int64))
+
+
+# ---------------------------------------------------------------------------------------------------
+# sampler
+# ---------------------------------------------------------------------------------------------------
+def _toy_csr(rng, n_users, n_items, dens):
+    pairs = np.argwhere(rng.rand(n_users, n_items) < dens)
+    return csr_from_pairs(pairs, n_users)
+
+
+def test_sampler_invariants_and_uniformity(ops, oracle):
+    rng = np.random.RandomState(0)
+    n_users, n_items, n_neg = 50, 97, 4000
+    ptr, idx = _toy_csr(rng, n_users, n_items, 0.3)
+    u = np.arange(n_users, dtype=np.int64)
+    status = ops.new_status('cuda')
+    neg = ops.sample_negatives_uniform(dev(ptr), dev(idx), n_items, dev(u), n_neg, seed=1234, stream_id=5,
+                                       status=status).cpu().numpy()
+    ops.raise_on_status(status)
+    assert neg.shape == (n_users, n_neg)
+    assert oracle.count_bad_negatives(ptr, idx, n_items, u, neg) == 0
+    # chi-square against the uniform law on each user's complement (df ~ 60-70 -> 99.99% quantile < 130)
+    for b in (0, 7, 33):
+        allowed = np.setdiff1d(np.arange(n_items), idx[ptr[b]:ptr[b + 1]])
+        cnt = np.bincount(neg[b], minlength=n_items)[allowed]
+        exp = n_neg / len(allowed)
+        chi2 = ((cnt - exp) ** 2 / exp).sum()
+        assert chi2 < 2.2 * len(allowed), (b, chi2, len(allowed))
+    # with replacement: duplicates exist; reproducible; a different stream gives a different draw
+    assert any(len(np.unique(neg[b])) < n_neg for b in range(n_users))
+    neg2 = ops.sample_negatives_uniform(dev(ptr), dev(idx), n_items, dev(u), n_neg, seed=1234, stream_id=5).cpu().numpy()
+    assert np.array_equal(neg, neg2)
+    neg3 = ops.sample_negatives_uniform(dev(ptr), dev(idx), n_items, dev(u), n_neg, seed=1234, stream_id=6).cpu().numpy()
+    assert not np.array_equal(neg, neg3)
+
+
+def test_sampler_same_law_as_reference_style_sampler(ops, oracle):
+    """Two-sample check against the numpy restatement of the reference's collate (different RNG, same law)."""
+    rng = np.random.RandomState(1)
+    n_users, n_items, n_neg = 8, 40, 20000
+    ptr, idx = _toy_csr(rng, n_users, n_items, 0.4)
+    u = np.arange(n_users, dtype=np.int64)
+    a = ops.sample_negatives_uniform(dev(ptr), dev(idx), n_items, dev(u), n_neg, seed=9).cpu().numpy()
+    b = oracle.sample_negatives_reference_style(np.random.RandomState(2), ptr, idx, n_items, u, n_neg)
+    for r in range(n_users):
+        ca = np.bincount(a[r], minlength=n_items).astype(np.float64)
+        cb = np.bincount(b[r], minlength=n_items).astype(np.float64)
+        assert np.array_equal(ca > 0, cb > 0) or (ca + cb)[(ca > 0) != (cb > 0)].max() < 5
+        sel = (ca + cb) > 0
+        chi2 = (((ca - cb) ** 2) / (ca + cb))[sel].sum()
+        assert chi2 < 2.5 * sel.sum(), (r, chi2, sel.sum())
+
+
+def test_sampler_user_with_all_items_gives_up(ops):
+    n_items = 16
+    ptr = np.array([0, n_items], dtype=np.int64)
+    idx = np.arange(n_items, dtype=np.int32)
+    status = ops.new_status('cuda')
+    ops.sample_negatives_uniform(dev(ptr), dev(idx), n_items, dev(np.zeros(1, np.int64)), 3, seed=1, status=status)
+    with pytest.raises(RuntimeError):
+        ops.raise_on_status(status)
+
+
+def test_fused_sampled_step_matches_oracle_on_its_own_batch(ops, oracle):
+    """Device-built batch: read back (u, i) the step used, check sampler invariants, replay in the oracle."""
+    rng = np.random.RandomState(3)
+    n_users, n_items, D, B, N = 120, 300, 64, 96, 20
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.05)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
+    st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=77, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                         coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+    tr = oracle.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], lr=1e-3, wd=1e-4)
+    order = torch.randperm(len(pairs), device='cuda')
+    prev = None
+    for s in range(3):
+        nb = B if s < 2 else 40  # ragged tail
+        st.step_sampled(order, s * B, nb, N)
+        u, i = st.last_batch(nb, N + 1)
+        u, i = u.cpu().numpy(), i.cpu().numpy()
+        sel = order[s * B:s * B + nb].cpu().numpy()
+        assert np.array_equal(u, pairs[sel, 0]) and np.array_equal(i[:, 0], pairs[sel, 1])
+        assert oracle.count_bad_negatives(ptr, idx, n_items, u, i[:, 1:]) == 0
+        if prev is not None:
+            assert not np.array_equal(prev, i[:40, 1:])  # fresh negatives every step
+        prev = i[:40, 1:].copy()
+        loss_ref, _, _, _ = tr.step(u, i)
+        assert abs(st.last_loss() - loss_ref) <= 1e-6 * loss_ref
+    for name in P:
+        assert_adam_param_close(t[name].cpu().numpy(), tr.P[name], name)
+    st.check_status()
+
+
+# ---------------------------------------------------------------------------------------------------
+# evaluation
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('split', ['val', 'test'])
+def test_eval_topk_metrics_vs_golden(ops, split):
+    fx = load_golden('g3_eval.npz')
+    U, I = dev(fx['param.user_embeddings.weight']), dev(fx['param.item_embeddings.weight'])
+    Ib, Ub = dev(fx['param.item_bias.weight'].reshape(-1)), dev(fx['param.user_bias.weight'].reshape(-1))
+    gb = dev(fx['param.global_bias'])
+    n_users = int(fx['n_users'])
+    excl = fx['train'] if split == 'val' else np.concatenate([fx['train'], fx['val']])
+    e_ptr, e_idx = csr_from_pairs(excl, n_users)
+    l_ptr, l_idx = csr_from_pairs(fx[split], n_users)
+    u = fx[f'{split}.u']
+    status = ops.new_status('cuda')
+    vals, ids, scores = ops.mf_eval_topk(U, I, Ib, Ub, gb, dev(u), 100, dev(e_ptr), dev(e_idx), status=status)
+    ops.raise_on_status(status)
+    sc, ref = scores.cpu().numpy(), fx[f'{split}.masked_logits']
+    assert np.array_equal(np.isinf(sc), np.isinf(ref))
+    fin = ~np.isinf(ref)
+    np.testing.assert_allclose(sc[fin], ref[fin], rtol=RTOL, atol=2e-6)
+    ids = ids.cpu().numpy()
+    ref_ids = fx[f'{split}.top100']
+    # same ranking except where two scores differ by less than fp32 rounding of the dot product
+    mism = ids != ref_ids
+    if mism.any():
+        r, c = np.nonzero(mism)
+        assert np.abs(ref[r, ids[r, c]] - ref[r, ref_ids[r, c]]).max() < 2e-6
+    assert mism.mean() < 0.01
+    assert np.all(np.diff(vals.cpu().numpy(), axis=1) <= 0)
+    ks = [5, 10, 50, 100]
+    met = ops.rank_metrics(ids_t := torch.from_numpy(ids).cuda(), dev(u), dev(l_ptr), dev(l_idx), ks).cpu().numpy()
+    del ids_t
+    names = [str(x) for x in fx[f'{split}.metric_names']]
+    got = {}
+    grp = fx['user_group'][u]
+    for t, k in enumerate(ks):
+        for j, nm in enumerate(('precision', 'recall', 'ndcg')):
+            got[f'{nm}@{k}'] = met[:, t, j].astype(np.float64).mean()
+            for g in (0, 1):
+                got[f'group_{g}_{nm}@{k}'] = met[grp == g, t, j].astype(np.float64).mean()
+    for name, val in zip(names, fx[f'{split}.metric_values']):
+        assert abs(got[name] - val) <= 1e-6 + 1e-4 * abs(val), name
+
+
+def test_eval_item_shards_merge_to_global_topk(ops):
+    """Item-sharded scoring + hsk_topk_merge == un-sharded top-k (the multi-GPU eval path on one device)."""
+    torch.manual_seed(0)
+    n_users, n_items, D, k = 70, 1000, 128, 100
+    U, I = torch.randn(n_users, D, device='cuda'), torch.randn(n_items, D, device='cuda')
+    Ib = torch.randn(n_items, device='cuda')
+    rng = np.random.RandomState(5)
+    e_ptr, e_idx = _toy_csr(rng, n_users, n_items, 0.1)
+    u = torch.arange(n_users, device='cuda')
+    v0, i0, _ = ops.mf_eval_topk(U, I, Ib, None, None, u, k, dev(e_ptr), dev(e_idx))
+    parts_v, parts_i = [], []
+    bounds = [0, 130, 400, 401, 777, 1000]  # uneven shards, one of them smaller than k
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        kk = min(k, hi - lo)
+        v, i, _ = ops.mf_eval_topk(U, I, Ib, None, None, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=hi - lo)
+        pad_v = torch.full((n_users, k), float('-inf'), device='cuda')
+        pad_i = torch.full((n_users, k), 2 ** 31 - 1, dtype=torch.int32, device='cuda')
+        pad_v[:, :kk], pad_i[:, :kk] = v, i
+        parts_v.append(pad_v)
+        parts_i.append(pad_i)
+    mv, mi = ops.topk_merge(torch.stack(parts_v).contiguous(), torch.stack(parts_i).contiguous())
+    assert torch.equal(mi, i0) and torch.equal(mv, v0)
+
+
+def test_topk_dense_ties_and_neg_inf(ops, oracle):
+    x = torch.zeros(5, 300, device='cuda')
+    x[0] = torch.arange(300, 0, -1)
+    x[1, :] = 1.0                       # all tied -> lowest indices
+    x[2, :] = float('-inf'); x[2, 7] = 3.; x[2, 250] = 3.; x[2, 100] = 5.   # fewer finite values than k
+    x[3] = torch.randn(300, device='cuda').round()   # many ties at the cut
+    x[4] = -torch.arange(300.)
+    vals, idx = ops.topk_dense(x, 100)
+    rv, ri = oracle.topk(x.cpu().numpy(), 100)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(vals.cpu().numpy(), rv)
+    assert idx.dtype == torch.int64
+
+
+def test_rank_metrics_vs_reference_functions(ops):
+    fx = load_golden('g5_metrics.npz')
+    y = fx['y_true']
+    R = y.shape[0]
+    ptr, idx = csr_from_pairs(np.argwhere(y > 0), R)
+    vals, ids = ops.topk_dense(dev(fx['logits']), 100)
+    assert np.array_equal(ids.cpu().numpy(), fx['top100'])
+    ks = [5, 10, 50, 100]
+    m = ops.rank_metrics(ids.to(torch.int32), torch.arange(R, device='cuda'), dev(ptr), dev(idx), ks).cpu().numpy()
+    for t, k in enumerate(ks):
+        for j, name in enumerate(('precision', 'recall', 'ndcg')):
+            np.testing.assert_allclose(m[:, t, j], fx[f'{name}@{k}'], rtol=1e-5, atol=1e-7, err_msg=f'{name}@{k}')
+
+
+def test_full_size_properties_cfg3(ops):
+    """BASELINE cfg3 shape (U=69878, I=10677, D=512, N=100, B=4096): size-independent properties.
+    (1) linearity: with lr -> tiny the loss of step 2 equals the loss of step 1 recomputed by the un-fused
+    operators; (2) every row moved (dense AdamW); (3) loss = log 2 at zero embeddings; (4) finite."""
+    torch.manual_seed(1)
+    U, I, D, B, N = 69878, 10677, 512, 4096, 100
+    P = {'user_emb': torch.randn(U, D, device='cuda') * (0.1 / D) * 50, 'item_emb': torch.randn(I, D, device='cuda') * (0.1 / D) * 50,
+         'item_bias': torch.randn(I, device='cuda') * 0.1}
+    st = ops.BprMfFusedState(P['user_emb'], P['item_emb'], P['item_bias'], lr=3e-4, wd=4e-5, max_batch=B, max_cols=N + 1)
+    u = torch.randint(0, U, (B,), device='cuda')
+    i = torch.randint(0, I, (B, N + 1), device='cuda')
+    logits = ops.mf_scores(P['user_emb'], P['item_emb'], P['item_bias'], None, None, u, i)
+    loss_unfused, _ = ops.bpr_loss_grad(logits, need_grad=False)
+    before_u = P['user_emb'][:64].clone()
+    st.step(u, i)
+    assert abs(st.last_loss() - loss_unfused.item()) <= 1e-6 * loss_unfused.item()
+    assert torch.isfinite(P['user_emb']).all() and torch.isfinite(P['item_emb']).all()
+    touched = torch.zeros(U, dtype=torch.bool, device='cuda')
+    touched[u] = True
+    moved = (P['user_emb'][:64] != before_u).any(dim=1)
+    # touched rows move by ~lr; untouched rows only decay by (1 - lr*wd)
+    assert moved[touched[:64]].all()
+    untouched = ~touched[:64]
+    if untouched.any():
+        ratio = (P['user_emb'][:64][untouched] / before_u[untouched])
+        assert torch.allclose(ratio, torch.full_like(ratio, 1 - 3e-4 * 4e-5), rtol=1e-6)
+    st.check_status()
+    # zero embeddings & biases -> every x = 0 -> loss = log 2
+    Z = {'user_emb': torch.zeros(1000, D, device='cuda'), 'item_emb': torch.zeros(I, D, device='cuda')}
+    st2 = ops.BprMfFusedState(Z['user_emb'], Z['item_emb'], None, lr=1e-3, wd=0.0, max_batch=B, max_cols=N + 1)
+    st2.step(torch.randint(0, 1000, (B,), device='cuda'), i)
+    assert abs(st2.last_loss() - np.log(2.0)) < 1e-7  # softplus evaluated in fp32

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import G1_CASES, PARAM_KEYS, csr_from_pairs, load_golden, max_norm_err
+from conftest import G1_CASES, PARAM_KEYS, assert_adam_param_close, csr_from_pairs, load_golden, max_norm_err
 
 RTOL = 1e-5  # BASELINE.json north_star: within 1e-5 relative fp32
 
@@ -43,7 +43,6 @@ def test_forward_loss_grads_match_reference(oracle, case):
 # Adam divides by sqrt(v)+eps: for gradient elements with |g| <~ eps (1e-8) a last-bit difference in the
 # fp32 gradient SUM (summation order) moves the parameter by up to ~lr*dg/(4*eps).  The optimiser arithmetic
 # itself is pinned to 1e-6 below (test_adamw_on_reference_grads); end-to-end tensors get this looser bound.
-ADAM_E2E_TOL = 5e-5
 
 
 def _diffs(logits):
@@ -70,9 +69,13 @@ def test_three_adamw_steps_match_reference(oracle, case):
                 if name in ('user_bias', 'global_bias') or name not in tr.P:
                     continue  # zero-gradient parameters: reference = amplified noise (hard part 2)
                 ref = fx[f's{step}.param.{sk}'].reshape(tr.P[name].shape)
-                assert max_norm_err(tr.P[name], ref) < ADAM_E2E_TOL, (step, name)
-                assert max_norm_err(tr.M[name], fx[f's{step}.m.{sk}'].reshape(ref.shape)) < RTOL, (step, name)
-                assert max_norm_err(tr.V[name], fx[f's{step}.v.{sk}'].reshape(ref.shape)) < RTOL, (step, name)
+                assert_adam_param_close(tr.P[name], ref, (step, name))
+                if step == 1:
+                    assert max_norm_err(tr.M[name], fx[f's{step}.m.{sk}'].reshape(ref.shape)) < RTOL, (step, name)
+                    assert max_norm_err(tr.V[name], fx[f's{step}.v.{sk}'].reshape(ref.shape)) < RTOL, (step, name)
+                else:
+                    assert_adam_param_close(tr.M[name], fx[f's{step}.m.{sk}'], (step, 'm', name))
+                    assert_adam_param_close(tr.V[name], fx[f's{step}.v.{sk}'], (step, 'v', name))
 
 
 @pytest.mark.parametrize('case', G1_CASES)
