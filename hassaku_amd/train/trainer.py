@@ -1,0 +1,184 @@
+"""Trainer -- drop-in for train/trainer.py:15-200 of the reference (same constructor, fit(), val(), log keys).
+
+What changes underneath:
+  * No nn.DataParallel and no per-step host synchronisation.  The reference calls `.item()` three times per
+    step (train/trainer.py:141-144) only to build per-epoch averages; here the per-step losses are summed on
+    the device and read once per epoch.
+  * When the model is the HIP SGDMatrixFactorization, the loss is BPR and the optimizer is AdamW, a whole
+    step (sampling, gathers, scores, loss, gradients, AdamW on every table) is ONE call into
+    libhassaku_hip.so (`hsk_bprmf_train_step[_sampled]`).  Set conf['fused_step'] = False to run the same
+    arithmetic through the un-fused operators + torch.optim (autograd path), e.g. for adam / adagrad.
+"""
+import logging
+from typing import Optional
+
+import torch
+from tqdm import trange
+
+from hassaku_amd import hip_ops
+from hassaku_amd.algorithms.base_classes import SGDBasedRecommenderAlgorithm
+from hassaku_amd.algorithms.sgd_alg import SGDMatrixFactorization
+from hassaku_amd.data.dataloader import TrainDataLoader
+from hassaku_amd.eval.eval import FullEvaluator, evaluate_recommender_algorithm
+from hassaku_amd.train.rec_losses import RecBayesianPersonalizedRankingLoss, RecommenderSystemLoss
+
+TORCH_OPTIMIZERS = {'adam': torch.optim.Adam, 'adagrad': torch.optim.Adagrad, 'adamw': torch.optim.AdamW}
+
+
+def _optional_module(name):
+    try:
+        return __import__(name)
+    except ImportError:
+        return None
+
+
+class Trainer:
+    def __init__(self, model: SGDBasedRecommenderAlgorithm, train_loader, val_loader, rec_loss: RecommenderSystemLoss,
+                 conf: dict):
+        self.train_loader, self.val_loader = train_loader, val_loader
+        self.device = conf['device']
+        if self.device != 'cuda':
+            raise RuntimeError("hassaku_amd trains on the HIP device only: set `device: cuda` in the conf "
+                               "(ROCm PyTorch names the MI355X 'cuda'); there is no CPU trainer")
+        hip_ops._lib.require_gpu()
+        self.model = self.pointer_to_model = model.to(self.device)
+        self.rec_loss = rec_loss
+        self.lr, self.wd = conf['lr'], conf['wd']
+        if conf['optimizer'] not in TORCH_OPTIMIZERS:
+            raise ValueError(f"Optimizer {conf['optimizer']} not yet implemented")
+
+        self.fused: Optional[hip_ops.BprMfFusedState] = None
+        want_fused = conf.get('fused_step', True)
+        if (want_fused and isinstance(model, SGDMatrixFactorization)
+                and isinstance(rec_loss, RecBayesianPersonalizedRankingLoss) and conf['optimizer'] == 'adamw'):
+            self.fused = self._build_fused(conf)
+            self.optimizer = None
+        else:
+            self.optimizer = TORCH_OPTIMIZERS[conf['optimizer']](self.model.parameters(), lr=self.lr,
+                                                                 weight_decay=self.wd)
+
+        self.n_epochs = conf['n_epochs']
+        self.optimizing_metric = conf['optimizing_metric']
+        self.max_patience = conf['max_patience']
+        self.model_path = conf['model_path']
+        running = conf['running_settings']
+        self.use_wandb, self.batch_verbose = running['use_wandb'], running['batch_verbose']
+        self._in_tune = conf.get('_in_tune', False)
+        self.best_value = self.best_metrics = self.best_epoch = None
+        logging.info('Built Trainer: epochs=%d loss=%s fused=%s optimizer=%s lr=%g wd=%g', self.n_epochs,
+                     rec_loss.name, self.fused is not None, conf['optimizer'], self.lr, self.wd)
+
+    # ------------------------------------------------------------------------------------------
+    def _build_fused(self, conf) -> hip_ops.BprMfFusedState:
+        user_emb, item_emb, ib, ub, gb = self.model.tables()
+        loader = self.train_loader
+        kw = {}
+        if isinstance(loader, TrainDataLoader):
+            kw = loader.dataset.device_arrays(torch.device(self.device))
+            max_batch, n_neg, seed = loader.batch_size, loader.interaction_sampler.n_neg, loader.seed
+        else:
+            max_batch, n_neg = conf['train_batch_size'], conf['neg_train']
+            seed = conf['running_settings'].get('seed', 64)
+        return hip_ops.BprMfFusedState(user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd, max_batch=max_batch,
+                                       max_cols=n_neg + 1, seed=seed, **kw)
+
+    def _log(self, log_dict):
+        if self.use_wandb and not self._in_tune:
+            wandb = _optional_module('wandb')
+            if wandb is not None:
+                wandb.log(log_dict)
+        if self._in_tune:
+            try:
+                from ray.air import session
+                session.report(log_dict)
+            except ImportError:
+                pass
+
+    def _post_val(self, epoch, log_dict):
+        hook = getattr(self.pointer_to_model, 'post_val', None)
+        if callable(hook):
+            log_dict.update(hook(epoch))
+
+    # ------------------------------------------------------------------------------------------
+    def _train_epoch_fused(self):
+        loader, fused = self.train_loader, self.fused
+        if isinstance(loader, TrainDataLoader):
+            n_neg = loader.interaction_sampler.n_neg
+            for order, start, nb in loader.fused_batches():
+                fused.step_sampled(order, start, nb, n_neg)
+        else:
+            for u_idxs, i_idxs, _labels in loader:
+                fused.step(u_idxs.to(self.device), i_idxs.to(self.device))
+        fused.flush()
+        rec = fused.pop_loss_sum() / len(loader)
+        fused.check_status()
+        return {'epoch_train_loss': rec, 'epoch_train_rec_loss': rec, 'epoch_train_reg_loss': 0.0}
+
+    def _train_epoch_autograd(self):
+        sums = None
+        for u_idxs, i_idxs, labels in self.train_loader:
+            u_idxs, i_idxs = u_idxs.to(self.device), i_idxs.to(self.device)
+            out = self.model(u_idxs, i_idxs)
+            rec = self.rec_loss.compute_loss(out, labels)
+            other = self.pointer_to_model.get_and_reset_other_loss()
+            reg = other['reg_loss'].to(rec.device)
+            total = rec + reg
+            step = torch.stack([total.detach().reshape(()).double(), rec.detach().reshape(()).double(),
+                                reg.detach().sum().double()])
+            sums = step if sums is None else sums + step   # stays on the device: one sync per epoch
+            total.backward()
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        total, rec, reg = (sums / len(self.train_loader)).tolist()
+        if isinstance(self.pointer_to_model, SGDMatrixFactorization):
+            self.pointer_to_model.check_indices()
+        return {'epoch_train_loss': total, 'epoch_train_rec_loss': rec, 'epoch_train_reg_loss': reg}
+
+    def fit(self):
+        patience = self.max_patience
+        log_dict = self.val()
+        self.best_value = log_dict['max_optimizing_metric'] = log_dict[self.optimizing_metric]
+        self.best_epoch = log_dict['best_epoch'] = -1
+        self.best_metrics = log_dict
+        self._post_val(-1, log_dict)
+        print('Init - Avg Val Value {:.3f} \n'.format(self.best_value))
+        self._log(log_dict)
+        self.pointer_to_model.save_model_to_path(self.model_path)
+
+        for epoch in trange(self.n_epochs, disable=not self.batch_verbose):
+            self.model.train()
+            if patience == 0:
+                print('Ran out of patience, Stopping ')
+                break
+            losses = self._train_epoch_fused() if self.fused is not None else self._train_epoch_autograd()
+            print('Epoch {} - Epoch Avg Train Loss {:.4f} ({:.4f} Rec Loss + {:.4f} Reg Loss )\n'.format(
+                epoch, losses['epoch_train_loss'], losses['epoch_train_rec_loss'], losses['epoch_train_reg_loss']))
+
+            metrics = self.val()
+            current = metrics[self.optimizing_metric]
+            print('Epoch {} - Avg Val Value {:.4f} \n'.format(epoch, current))
+            if current > self.best_value:
+                self.best_value = metrics['max_optimizing_metric'] = current
+                self.best_epoch = metrics['best_epoch'] = epoch
+                self.best_metrics = metrics
+                print('Epoch {} - New best model found (val value {:.4f}) \n'.format(epoch, current))
+                self.pointer_to_model.save_model_to_path(self.model_path)
+                patience = self.max_patience
+            else:
+                metrics['max_optimizing_metric'] = self.best_value
+                patience -= 1
+            log_dict = {**metrics, **losses}
+            self._post_val(epoch, log_dict)
+            self._log(log_dict)
+        return self.best_metrics
+
+    @torch.no_grad()
+    def val(self):
+        self.model.eval()
+        if self.fused is not None:
+            self.fused.flush()
+        dataset = self.val_loader.dataset
+        evaluator = FullEvaluator(aggr_by_group=True, n_groups=dataset.n_user_groups,
+                                  user_to_user_group=dataset.user_to_user_group)
+        return evaluate_recommender_algorithm(self.pointer_to_model, self.val_loader, evaluator, self.device,
+                                              self.batch_verbose)

@@ -1,0 +1,329 @@
+"""CPU-only tests of the host side: C-ABI surface, conf parsing, datasets, loaders, generic metrics,
+and that the product refuses to compute without the HIP device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+
+
+# ---------------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------------
+def _declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'hassaku_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(hsk_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hassaku_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/hassaku_hip.h but not exported'
+    assert sorted(_lib.SIGNATURES) == declared, 'ctypes prototypes out of sync with the header'
+    loaded = _lib.load()
+    assert loaded.hsk_version() >= 100
+    assert loaded.hsk_last_error() is not None
+
+
+def test_state_struct_layout_matches_header():
+    """Field order of the ctypes mirror == field order of `struct hsk_bprmf_state` in the header."""
+    from hassaku_amd._lib import HskBprmfState
+    text = open(os.path.join(REPO, 'include', 'hassaku_hip.h')).read()
+    body = text[text.index('typedef struct hsk_bprmf_state {'):text.index('} hsk_bprmf_state;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl or '{' in decl:
+            decl = decl.split('{')[-1].strip()
+            if not decl:
+                continue
+        for part in decl.split(','):
+            m = re.search(r'([A-Za-z_][A-Za-z0-9_]*)\s*$', part.strip())
+            if m:
+                names.append(m.group(1))
+    assert names == [f[0] for f in HskBprmfState._fields_]
+
+
+def test_workspace_size_is_pure_host_arithmetic():
+    from hassaku_amd import _lib
+    lib = _lib.load()
+    small = lib.hsk_bprmf_workspace_bytes(100, 200, 64, 32, 11)
+    big = lib.hsk_bprmf_workspace_bytes(100, 200, 64, 64, 11)
+    assert 0 < small < big and small % 256 == 0
+    assert lib.hsk_bprmf_workspace_bytes(0, 200, 64, 32, 11) < 0
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from hassaku_amd import hip_ops
+    from hassaku_amd.algorithms.sgd_alg import SGDMatrixFactorization
+    with pytest.raises(RuntimeError):
+        hip_ops.mf_scores(torch.randn(4, 8), torch.randn(4, 8), None, None, None, torch.zeros(1, dtype=torch.int64),
+                          torch.zeros((1, 2), dtype=torch.int64))
+    model = SGDMatrixFactorization(5, 7, 8, False, True, False)
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, dtype=torch.int64), torch.zeros((2, 3), dtype=torch.int64))
+    from hassaku_amd.train.trainer import Trainer
+    from hassaku_amd.train.rec_losses import RecBayesianPersonalizedRankingLoss
+    conf = {'device': 'cpu', 'lr': 1e-3, 'wd': 0., 'optimizer': 'adamw', 'n_epochs': 1, 'optimizing_metric': 'ndcg@10',
+            'max_patience': 1, 'model_path': '/tmp', 'running_settings': {'use_wandb': False, 'batch_verbose': False}}
+    with pytest.raises(RuntimeError):
+        Trainer(model, [], None, RecBayesianPersonalizedRankingLoss(), conf)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, 'hassaku_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(root, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M) or 'liboracle' in text:
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------------
+# model surface
+# ---------------------------------------------------------------------------------------------------
+def test_state_dict_keys_shapes_and_init_match_reference():
+    from hassaku_amd.algorithms.sgd_alg import SGDMatrixFactorization
+    fx = load_golden('g1_step_d64_all.npz')
+    torch.manual_seed(64)
+    m = SGDMatrixFactorization(int(fx['n_users']), int(fx['n_items']), int(fx['dim']), True, True, True)
+    sd = m.state_dict()
+    assert sorted(sd) == ['global_bias', 'item_bias.weight', 'item_embeddings.weight', 'user_bias.weight',
+                          'user_embeddings.weight']
+    for k, v in sd.items():
+        ref = fx['init.' + k]
+        assert tuple(v.shape) == ref.shape, k
+        assert np.array_equal(v.numpy(), ref), f'{k}: initialisation differs from the reference under the same seed'
+    fx2 = load_golden('g1_step_d402_item.npz')
+    torch.manual_seed(64)
+    m2 = SGDMatrixFactorization(int(fx2['n_users']), int(fx2['n_items']), 402, False, True, False)
+    assert sorted(m2.state_dict()) == ['item_bias.weight', 'item_embeddings.weight', 'user_embeddings.weight']
+    assert np.array_equal(m2.state_dict()['item_embeddings.weight'].numpy(), fx2['init.item_embeddings.weight'])
+    assert m2.get_and_reset_other_loss()['reg_loss'].shape == (1,)
+
+
+def test_loss_registry_and_unbuilt_losses():
+    from hassaku_amd.train.rec_losses import RecommenderSystemLossesEnum
+    assert [m.name for m in RecommenderSystemLossesEnum] == ['bce', 'bpr', 'sampled_softmax']
+    loss = RecommenderSystemLossesEnum['bpr'].value.build_from_conf({}, None)
+    assert loss.name == 'RecBayesianPersonalizedRankingLoss'
+    with pytest.raises(NotImplementedError):
+        RecommenderSystemLossesEnum['bce'].value.build_from_conf({}, None)
+
+
+# ---------------------------------------------------------------------------------------------------
+# conf
+# ---------------------------------------------------------------------------------------------------
+def test_parse_conf_defaults_and_validation(tmp_path):
+    from hassaku_amd.algorithms.algorithms_utils import AlgorithmsEnum
+    from hassaku_amd.conf.conf_parser import parse_conf, parse_conf_file, save_yaml
+    from hassaku_amd.data.data_utils import DatasetsEnum
+    conf = parse_conf({'data_path': str(tmp_path), 'model_save_path': str(tmp_path / 'models'), 'n_epochs': 7},
+                      AlgorithmsEnum.mf, DatasetsEnum.ml1m)
+    assert conf['alg'] == 'mf' and conf['dataset'] == 'ml1m'
+    assert conf['dataset_path'] == os.path.join(str(tmp_path), 'ml1m', 'processed_dataset')
+    assert os.path.isdir(conf['model_path']) and '/mf-ml1m/single_runs/' in conf['model_path']
+    assert (conf['neg_train'], conf['train_neg_strategy'], conf['train_batch_size'], conf['eval_batch_size']) == (4, 'uniform', 64, 64)
+    assert (conf['lr'], conf['wd'], conf['optimizer'], conf['rec_loss'], conf['device']) == (1e-3, 0, 'adam', 'bce', 'cpu')
+    assert conf['optimizing_metric'] == 'ndcg@10' and conf['max_patience'] == 6
+    rs = conf['running_settings']
+    assert (rs['seed'], rs['use_wandb'], rs['batch_verbose'], rs['train_n_workers'], rs['eval_n_workers']) == (64, True, False, 2, 2)
+    for bad in ({'optimizer': 'sgd'}, {'device': 'tpu'}, {'rec_loss': 'hinge'}, {'n_epochs': 5, 'max_patience': 5},
+                {'n_epochs': 0}):
+        with pytest.raises(AssertionError):
+            parse_conf({'data_path': str(tmp_path), 'model_save_path': str(tmp_path / 'm'), **bad},
+                       AlgorithmsEnum.mf, DatasetsEnum.ml1m)
+    with pytest.raises(AssertionError):
+        parse_conf({}, AlgorithmsEnum.mf, DatasetsEnum.ml1m)
+    save_yaml(conf['model_path'], conf)
+    again = parse_conf_file(os.path.join(conf['model_path'], 'conf.yml'))
+    assert again['n_epochs'] == 7 and again['running_settings']['seed'] == 64
+    (tmp_path / 'c.json').write_text('{"data_path": "x", "lr": 0.5}')
+    assert parse_conf_file(str(tmp_path / 'c.json'))['lr'] == 0.5
+    assert 'ml100k' in DatasetsEnum.__members__
+
+
+# ---------------------------------------------------------------------------------------------------
+# data
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def toy_dir(tmp_path_factory):
+    from hassaku_amd.data.synthetic import generate, write_csv_dataset
+    path = str(tmp_path_factory.mktemp('toy'))
+    data = generate(40, 130, 900, seed=1, n_groups=2)
+    write_csv_dataset(data, path)
+    return path, data
+
+
+def test_synthetic_split_rule(toy_dir):
+    _, d = toy_dir
+    import math
+    for u in (0, 7, 39):
+        n_tr, n_va, n_te = [(getattr(d, s)[:, 0] == u).sum() for s in ('train', 'val', 'test')]
+        n = n_tr + n_va + n_te
+        assert n_va == n_te == math.ceil(0.1 * n)          # data/data_utils.py:302-304 of the reference
+        items = np.concatenate([getattr(d, s)[getattr(d, s)[:, 0] == u, 1] for s in ('train', 'val', 'test')])
+        assert len(np.unique(items)) == n
+
+
+def test_train_dataset_matches_reference_contract(toy_dir):
+    from hassaku_amd.data.dataset import TrainRecDataset
+    path, d = toy_dir
+    ds = TrainRecDataset(path)
+    assert (ds.n_users, ds.n_items, ds.n_user_groups) == (40, 130, 2)
+    assert len(ds) == len(d.train) == ds.iteration_matrix.nnz
+    u, i, lab = ds[5]
+    assert (u, i, lab) == (d.train[5, 0], d.train[5, 1], 1.) and u.dtype == np.int64
+    assert abs(ds.pop_distribution.sum() - 1) < 1e-12
+    np.testing.assert_allclose(ds.pop_distribution * len(d.train), np.bincount(d.train[:, 1], minlength=130), rtol=1e-12)
+    csr = ds.sampling_csr
+    for r in (0, 11, 39):
+        assert np.array_equal(csr.row(r), np.sort(d.train[d.train[:, 0] == r, 1]))
+    sp = ds.sampling_matrix
+    assert sp.shape == (40, 130) and np.array_equal(sp.indptr, csr.indptr) and np.array_equal(sp.indices, csr.indices)
+    assert ds.user_to_user_group.dtype == torch.float32 and ds.user_to_user_group.shape == (40,)
+
+
+def test_eval_dataset_exclusion_sets(toy_dir):
+    from hassaku_amd.data.dataset import FullEvalDataset
+    path, d = toy_dir
+    val, test = FullEvalDataset(path, 'val'), FullEvalDataset(path, 'test')
+    assert len(val) == 40
+    for r in (3, 20):
+        tr = set(d.train[d.train[:, 0] == r, 1])
+        va = set(d.val[d.val[:, 0] == r, 1])
+        assert set(val.exclude_csr.row(r)) == tr and set(test.exclude_csr.row(r)) == tr | va
+        assert set(val.label_csr.row(r)) == va
+        u, items, labels = val[r]
+        assert u == r and np.array_equal(items, np.arange(130)) and labels.dtype == np.float32
+        assert set(np.nonzero(labels)[0]) == va
+    assert val.exclude_data.shape == (40, 130) and val.exclude_data.dtype == bool
+    with pytest.raises(AssertionError):
+        FullEvalDataset(path, 'train')
+
+
+def test_csr_rejects_out_of_grid_pairs():
+    from hassaku_amd.data.csr import UserItemCsr
+    with pytest.raises(ValueError):
+        UserItemCsr.from_pairs([0, 5], [1, 2], 5, 10)
+    c = UserItemCsr.from_pairs([1, 1, 0, 1], [4, 2, 9, 4], 3, 10)   # duplicate (1,4) collapses
+    assert c.nnz == 3 and list(c.row(1)) == [2, 4] and list(c.row(2)) == []
+    u = c.union(UserItemCsr.from_pairs([2], [0], 3, 10))
+    assert u.nnz == 4 and list(u.row(2)) == [0]
+
+
+def test_train_loader_lengths_and_sampler_validation(toy_dir):
+    from hassaku_amd.data.dataloader import NegativeSampler, TrainDataLoader
+    from hassaku_amd.data.dataset import TrainRecDataset
+    path, d = toy_dir
+    ds = TrainRecDataset(path)
+    n = len(ds)
+    loader = TrainDataLoader(NegativeSampler(ds, 5), ds, batch_size=64, shuffle=False, device='cpu')
+    assert len(loader) == -(-n // 64)
+    plan = list(loader.fused_batches())
+    assert plan[0] == (None, 0, 64) and plan[-1][2] == n - 64 * (len(plan) - 1) and sum(p[2] for p in plan) == n
+    assert len(TrainDataLoader(NegativeSampler(ds, 5), ds, batch_size=64, drop_last=True, device='cpu')) == n // 64
+    with pytest.raises(AssertionError):
+        NegativeSampler(ds, 0)
+    with pytest.raises(AssertionError):
+        NegativeSampler(ds, 3, 'zipf')
+    with pytest.raises(NotImplementedError):
+        NegativeSampler(ds, 3, 'popular')
+    with pytest.raises(ValueError):
+        TrainDataLoader(object(), ds, batch_size=8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# generic (dense) metrics + evaluator on CPU tensors
+# ---------------------------------------------------------------------------------------------------
+def test_dense_metrics_match_reference_functions():
+    from hassaku_amd.eval.metrics import ndcg_at_k_batch, precision_at_k_batch, recall_at_k_batch
+    fx = load_golden('g5_metrics.npz')
+    logits, y = torch.from_numpy(fx['logits']), torch.from_numpy(fx['y_true'])
+    for k in (5, 10, 50, 100):
+        for name, fn in (('precision', precision_at_k_batch), ('recall', recall_at_k_batch), ('ndcg', ndcg_at_k_batch)):
+            got = fn(logits, y, k, aggr_sum=False).numpy()
+            np.testing.assert_allclose(got, fx[f'{name}@{k}'], rtol=1e-5, atol=1e-7, err_msg=f'{name}@{k}')
+            assert abs(fn(logits, y, k).item() - fx[f'{name}@{k}'].sum()) < 1e-4
+    with pytest.raises(AssertionError):
+        precision_at_k_batch(logits, y, 10, idx_topk=torch.zeros((12, 5), dtype=torch.int64))
+
+
+def test_dense_metric_known_answers():
+    """The closed-form cases of the reference's unit test (framework_tests/eval/test_metrics.py:10-69)."""
+    import math
+    from hassaku_amd.eval.metrics import ndcg_at_k_batch, precision_at_k_batch, recall_at_k_batch
+    R, I, k = 10, 20, 10
+    logits = torch.arange(I, 0, -1).repeat(R, 1).float()
+
+    def y(cols):
+        t = torch.zeros((R, I))
+        t[:, list(cols)] = 1
+        return t
+
+    def mean(fn, cols):
+        return fn(logits, y(cols), k=k).item() / R
+
+    disc = 1. / torch.log2(torch.arange(2, k + 2).float())
+    assert mean(recall_at_k_batch, []) == 0 and mean(precision_at_k_batch, []) == 0 and mean(ndcg_at_k_batch, []) == 0
+    assert abs(mean(recall_at_k_batch, range(I)) - k / I) < 1e-6
+    assert mean(precision_at_k_batch, range(I)) == 1 and mean(ndcg_at_k_batch, range(I)) == 1
+    assert mean(recall_at_k_batch, [0]) == 1 and abs(mean(precision_at_k_batch, [0]) - 1 / k) < 1e-6
+    assert mean(ndcg_at_k_batch, [0]) == 1
+    assert mean(recall_at_k_batch, [1, 2]) == 1 and abs(mean(precision_at_k_batch, [1, 2]) - 2 / k) < 1e-6
+    assert abs(mean(ndcg_at_k_batch, [1, 2]) - (math.log2(4) + math.log2(3)) / (math.log2(4) * (1 + math.log2(3)))) < 1e-5
+    out_of_k = [0] + list(range(k + 1, I))
+    assert abs(mean(recall_at_k_batch, out_of_k) - 1 / (I - k)) < 1e-6
+    assert abs(mean(precision_at_k_batch, out_of_k) - 1 / k) < 1e-6
+    assert abs(mean(ndcg_at_k_batch, out_of_k) - 1 / disc[:min(k, I - k)].sum().item()) < 1e-5
+
+
+def test_full_evaluator_group_aggregation():
+    from hassaku_amd.eval.eval import FullEvaluator
+    fx = load_golden('g5_metrics.npz')
+    logits, y = torch.from_numpy(fx['logits']), torch.from_numpy(fx['y_true'])
+    groups = torch.tensor([0, 1] * 6, dtype=torch.float32)
+    ev = FullEvaluator(aggr_by_group=True, n_groups=2, user_to_user_group=groups)
+    ev.eval_batch(torch.arange(0, 7), logits[:7], y[:7])
+    ev.eval_batch(torch.arange(7, 12), logits[7:], y[7:])
+    res = ev.get_results()
+    assert len(res) == 36
+    assert abs(res['ndcg@10'] - fx['ndcg@10'].mean()) < 1e-6
+    assert abs(res['group_0_recall@50'] - fx['recall@50'][0::2].mean()) < 1e-6
+    assert abs(res['group_1_precision@5'] - fx['precision@5'][1::2].mean()) < 1e-6
+    assert ev.get_results() == {}  # reset after reading
+
+
+# ---------------------------------------------------------------------------------------------------
+# the CPU-baseline port is the reference's arithmetic
+# ---------------------------------------------------------------------------------------------------
+def test_cpu_trainer_port_matches_reference():
+    from oracle.cpu_trainer import CpuTrainer
+    from conftest import assert_adam_param_close
+    fx = load_golden('g1_step_d64_item.npz')
+    U, I, D = int(fx['n_users']), int(fx['n_items']), int(fx['dim'])
+    tr = CpuTrainer(U, I, D, float(fx['lr']), float(fx['wd']), None, None, None, None, 7, 16, seed=64, threads=1)
+    sd = tr.model.state_dict()
+    for k in sd:   # same seed, same construction order -> same init as the reference
+        assert np.array_equal(sd[k].numpy(), fx['init.' + k]), k
+    for step in (1, 2, 3):
+        labels = torch.zeros(fx[f's{step}.i_idx'].shape, dtype=torch.float64)
+        labels[:, 0] = 1
+        loss = tr.step_on(torch.from_numpy(fx[f's{step}.u_idx']), torch.from_numpy(fx[f's{step}.i_idx']), labels)
+        # total = rec (f64 scalar) + reg (f32 [1]) is f32 in the reference too (train/trainer.py:139)
+        assert abs(loss - float(fx[f's{step}.loss'])) < 1e-7
+    for k, v in tr.model.state_dict().items():
+        assert_adam_param_close(v.numpy(), fx['s3.param.' + k], k)
