@@ -1,0 +1,388 @@
+// hsk_fused.hip -- the fused BPR-MF AdamW training step of the C ABI (hsk_bprmf_*): workspace layout,
+// per-stage HIP-event timing, and the launch sequence
+//
+//   prep     loader batch -> int32 copies   |   device batch: COO gather + uniform rejection sampler
+//   sort     hist -> scan -> scatter -> bucket sort   (entries grouped by item, deterministic)
+//   fwd      k_fwd_ugrad      gather + scores + BPR + user-row gradient      (the roofline kernel)
+//   item     k_item_update    item-major gradient reduction + AdamW on every item row
+//   user     k_user_update[_lazy]  AdamW on the user table (dense sweep, or exact lazy catch-up)
+//   finish   loss reduction, global bias
+//
+// Reference semantics: one iteration of the loop at train/trainer.py:128-148 of the reference.
+#include "hsk_sampler.h"
+#include "hsk_sort.h"
+#include "hsk_step_kernels.h"
+
+#include <vector>
+
+#define HSK_ADAM_TAB_LEN 65536   // per-step (step_size, bc2_sqrt) table for the lazy replay
+#define HSK_FLUSH_EVERY 64       // lazy mode: dense catch-up sweep every this many steps (bounds the replay length)
+
+// =============================================================================================
+// workspace carving
+// =============================================================================================
+struct hsk_ws {
+  int* u32;
+  int* it32;
+  float* g_s;
+  int2* perm1;
+  int* perm;
+  int* hist;
+  int* btot;
+  int* bstart;
+  int* offsets;
+  int* owner;
+  int* cnt;
+  int* last_step;
+  float* dUb;
+  double* loss_b;
+  float2* adam_tab;
+  int64_t total;
+};
+
+static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
+                        int64_t max_cols) {
+  hsk_ws w;
+  char* p = (char*)base;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += hsk_align_up(bytes, 256);
+    return r;
+  };
+  const int64_t ent = max_batch * max_cols;
+  const int64_t hist_elems = hsk_sort_hist_elems(n_items, ent);
+  w.u32 = (int*)take(max_batch * 4);
+  w.it32 = (int*)take(ent * 4);
+  w.g_s = (float*)take(ent * 4);
+  w.perm1 = (int2*)take(ent * 8);
+  w.perm = (int*)take(ent * 4);
+  w.hist = (int*)take((hist_elems > 0 ? hist_elems : 4) * 4);
+  w.btot = (int*)take(HSK_SORT_MAX_BUCKETS * 4);
+  w.bstart = (int*)take((HSK_SORT_MAX_BUCKETS + 1) * 4);
+  w.offsets = (int*)take((n_items + 1) * 4);
+  w.owner = (int*)take(n_users * 4);
+  w.cnt = (int*)take(n_users * 4);
+  w.last_step = (int*)take(n_users * 4);
+  w.dUb = (float*)take(max_batch * dim * 4);
+  w.loss_b = (double*)take(max_batch * 8);
+  w.adam_tab = (float2*)take((HSK_ADAM_TAB_LEN + 1) * sizeof(float2));
+  w.total = off;
+  return w;
+}
+
+extern "C" int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
+                                             int64_t max_cols) {
+  if (n_users <= 0 || n_items <= 0 || dim <= 0 || max_batch <= 0 || max_cols <= 1) return -1;
+  if (hsk_sort_hist_elems(n_items, max_batch * max_cols) < 0) return -1;
+  return hsk_carve(nullptr, n_users, n_items, dim, max_batch, max_cols).total;
+}
+
+// lazy replay needs the per-step scalars to be constant beyond the table
+static bool hsk_adam_tab_saturates(const hsk_bprmf_state* st) {
+  const hsk_adamw_consts a = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, HSK_ADAM_TAB_LEN);
+  const hsk_adamw_consts b = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, (int64_t)1 << 40);
+  return a.step_size == b.step_size && a.bc2_sqrt == b.bc2_sqrt && a.rbc2_sqrt == b.rbc2_sqrt;
+}
+
+static int hsk_check_state(const hsk_bprmf_state* st) {
+  HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
+  HSK_REQUIRE(st->user_emb && st->item_emb && st->m_user_emb && st->v_user_emb && st->m_item_emb && st->v_item_emb,
+              HSK_ERR_INVALID, "embedding / moment pointers must not be NULL");
+  HSK_REQUIRE(!st->item_bias || (st->m_item_bias && st->v_item_bias), HSK_ERR_INVALID, "item_bias moments missing");
+  HSK_REQUIRE(!st->user_bias || (st->m_user_bias && st->v_user_bias), HSK_ERR_INVALID, "user_bias moments missing");
+  HSK_REQUIRE(!st->global_bias || (st->m_global_bias && st->v_global_bias), HSK_ERR_INVALID,
+              "global_bias moments missing");
+  HSK_REQUIRE(st->n_users > 0 && st->n_items > 0 && st->dim > 0, HSK_ERR_INVALID, "bad table shape");
+  HSK_REQUIRE(st->n_users < 0x7fffffff && st->n_items < 0x7fffffff, HSK_ERR_UNSUPPORTED, "tables too large for int32 ids");
+  HSK_REQUIRE(st->max_batch > 0 && st->max_cols >= 2 && st->max_batch * st->max_cols < 0x7fffffff, HSK_ERR_INVALID,
+              "bad max_batch / max_cols");
+  HSK_REQUIRE(st->workspace != nullptr, HSK_ERR_INVALID, "workspace is NULL");
+  const int64_t need = hsk_bprmf_workspace_bytes(st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  HSK_REQUIRE(need > 0, HSK_ERR_UNSUPPORTED, "n_items %lld too large for the item sort (max %d per device)",
+              (long long)st->n_items, HSK_SORT_MAX_BUCKETS * HSK_SORT_MAX_IPB);
+  HSK_REQUIRE(st->workspace_bytes >= need, HSK_ERR_INVALID, "workspace too small: %lld < %lld",
+              (long long)st->workspace_bytes, (long long)need);
+  HSK_REQUIRE(((uintptr_t)st->workspace & 255) == 0, HSK_ERR_INVALID, "workspace must be 256-byte aligned");
+  const int V = (st->dim % 4 == 0) ? 4 : (st->dim % 2 == 0) ? 2 : 1;
+  HSK_REQUIRE((((uintptr_t)st->user_emb | (uintptr_t)st->item_emb | (uintptr_t)st->m_user_emb |
+                (uintptr_t)st->v_user_emb | (uintptr_t)st->m_item_emb | (uintptr_t)st->v_item_emb) &
+               (uintptr_t)(4 * V - 1)) == 0,
+              HSK_ERR_INVALID, "tables must be %d-byte aligned", 4 * V);
+  HSK_REQUIRE(st->lazy_users == 0 || st->lazy_users == 1, HSK_ERR_INVALID, "lazy_users must be 0 or 1");
+  HSK_REQUIRE(st->lazy_users == 0 || hsk_adam_tab_saturates(st), HSK_ERR_UNSUPPORTED,
+              "lazy_users needs bias corrections that saturate within %d steps (betas too close to 1)",
+              HSK_ADAM_TAB_LEN);
+  HSK_REQUIRE(st->step >= 0 && st->step < 0x7ffffff0, HSK_ERR_UNSUPPORTED, "step counter out of range");
+  return HSK_OK;
+}
+
+extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t stream_) {
+  int rc = hsk_check_state(st);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  HSK_HIP(hipMemsetAsync(w.cnt, 0, st->n_users * 4, stream));
+  k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner, st->n_users, HSK_OWNER_NONE);
+  HSK_LAUNCH_CHECK();
+  // rows are current up to the steps already applied (0 for a fresh optimiser)
+  k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.last_step, st->n_users, (int)st->step);
+  HSK_LAUNCH_CHECK();
+  if (st->loss_out) HSK_HIP(hipMemsetAsync(st->loss_out, 0, 2 * sizeof(double), stream));
+  if (st->status) HSK_HIP(hipMemsetAsync(st->status, 0, sizeof(int32_t), stream));
+  // per-step scalars, computed on the host by the same routine every step uses (one-time, synchronous)
+  std::vector<float2> tab(HSK_ADAM_TAB_LEN + 1);
+  tab[0] = make_float2(0.f, 1.f);
+  for (int t = 1; t <= HSK_ADAM_TAB_LEN; ++t) {
+    const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, t);
+#if HSK_ADAM_IEEE
+    tab[t] = make_float2(c.step_size, c.bc2_sqrt);
+#else
+    tab[t] = make_float2(c.step_size, c.rbc2_sqrt);
+#endif
+  }
+  HSK_HIP(hipMemcpyAsync(w.adam_tab, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice, stream));
+  HSK_HIP(hipStreamSynchronize(stream));
+  return HSK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-stage HIP-event timing (host-side recorder; events are recorded on the kernels' own stream)
+// ---------------------------------------------------------------------------------------------
+struct hsk_timing {
+  std::vector<hipEvent_t> beg[HSK_STAGE_COUNT], end[HSK_STAGE_COUNT];
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+
+extern "C" void* hsk_timing_create(void) { return new hsk_timing(); }
+
+extern "C" void hsk_timing_destroy(void* t_) {
+  hsk_timing* t = (hsk_timing*)t_;
+  if (!t) return;
+  for (int s = 0; s < HSK_STAGE_COUNT; ++s) {
+    for (hipEvent_t e : t->beg[s]) (void)hipEventDestroy(e);
+    for (hipEvent_t e : t->end[s]) (void)hipEventDestroy(e);
+  }
+  for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
+  delete t;
+}
+
+extern "C" int hsk_timing_collect(void* t_, double* ms_sum, int64_t* count) {
+  hsk_timing* t = (hsk_timing*)t_;
+  HSK_REQUIRE(t && ms_sum && count, HSK_ERR_INVALID, "NULL argument");
+  for (int s = 0; s < HSK_STAGE_COUNT; ++s) {
+    for (size_t i = 0; i < t->end[s].size(); ++i) {
+      HSK_HIP(hipEventSynchronize(t->end[s][i]));
+      float ms = 0.f;
+      HSK_HIP(hipEventElapsedTime(&ms, t->beg[s][i], t->end[s][i]));
+      ms_sum[s] += (double)ms;
+      count[s] += 1;
+      t->pool.push_back(t->beg[s][i]);
+      t->pool.push_back(t->end[s][i]);
+    }
+    t->beg[s].clear();
+    t->end[s].clear();
+  }
+  return HSK_OK;
+}
+
+static inline void hsk_stage_mark(const hsk_bprmf_state* st, int stage, bool begin, hipStream_t stream) {
+  hsk_timing* t = (hsk_timing*)st->timing;
+  if (!t || !((st->timing_mask >> stage) & 1)) return;
+  hipEvent_t e = t->get();
+  if (!e) return;
+  (void)hipEventRecord(e, stream);
+  (begin ? t->beg[stage] : t->end[stage]).push_back(e);
+}
+
+#define HSK_STAGE(stage, ...)                      \
+  do {                                             \
+    hsk_stage_mark(st, (stage), true, stream);     \
+    __VA_ARGS__;                                   \
+    hsk_stage_mark(st, (stage), false, stream);    \
+  } while (0)
+
+// =============================================================================================
+// launch sequence
+// =============================================================================================
+static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream) {
+  const int U = (int)st->n_users, D = (int)st->dim;
+  if (st->step == 0) return HSK_OK;
+  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
+  int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
+    constexpr int V = decltype(v_)::value;
+    constexpr int NCH = decltype(n_)::value;
+    constexpr bool FULL = decltype(f_)::value;
+    k_user_flush<V, NCH, FULL><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
+        st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias, st->v_user_bias, w.last_step, U,
+        D, (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN);
+    return HSK_OK;
+  });
+  if (rc) return rc;
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+// stages after prep filled u32 / it32 / owner / cnt
+static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t K, hipStream_t stream) {
+  const int64_t total = B * K;
+  const int I = (int)st->n_items, U = (int)st->n_users, D = (int)st->dim;
+  st->step += 1;
+  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
+  const double inv_bn_d = 1.0 / ((double)B * (double)(K - 1));
+  const float inv_bn = (float)inv_bn_d;
+
+  hsk_sort_plan plan;
+  HSK_REQUIRE(hsk_make_sort_plan(I, total, &plan) == 0, HSK_ERR_UNSUPPORTED, "item sort: n_items too large");
+  const size_t bucket_lds = (size_t)5 * plan.ipb * sizeof(int);
+  if (bucket_lds > 65536)
+    HSK_HIP(hipFuncSetAttribute((const void*)k_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds));
+  HSK_STAGE(HSK_STAGE_SCAN, {
+    k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist);
+    k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
+  });
+  HSK_LAUNCH_CHECK();
+  HSK_STAGE(HSK_STAGE_SCATTER, {
+    k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist,
+                                                                                 w.btot, w.perm1, w.bstart);
+    k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(w.perm1, (int)total, I, plan, w.bstart, w.perm,
+                                                                         w.offsets);
+  });
+  HSK_LAUNCH_CHECK();
+
+  int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
+    constexpr int V = decltype(v_)::value;
+    constexpr int NCH = decltype(n_)::value;
+    constexpr bool FULL = decltype(f_)::value;
+    constexpr int R = (V * NCH >= 16) ? 2 : 4;
+    if (st->lazy_users) {
+      // the forward must read current rows: replay the missed zero-gradient steps of this batch's users first
+      HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<V, NCH, FULL><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
+                                    st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
+                                    st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,
+                                    w.adam_tab, HSK_ADAM_TAB_LEN)));
+    }
+    HSK_STAGE(HSK_STAGE_FWD, (k_fwd_ugrad<V, NCH, FULL, R><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
+                                 st->user_emb, st->item_emb, st->item_bias, w.u32, w.it32, (int)B, (int)K, D, inv_bn,
+                                 w.g_s, w.dUb, w.loss_b)));
+    HSK_STAGE(HSK_STAGE_ITEM, (k_item_update<V, NCH, FULL, R, true><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
+                                  st->user_emb, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb,
+                                  st->m_item_bias, st->v_item_bias, w.u32, w.g_s, w.perm, w.offsets, I, (int)K, D, c,
+                                  nullptr, nullptr)));
+    if (st->lazy_users) {
+      HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
+                                    st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
+                                    st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,
+                                    (int)st->step, c)));
+    } else {
+      HSK_STAGE(HSK_STAGE_USER, (k_user_update<V, NCH, FULL, 0><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
+                                    st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
+                                    st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, U, (int)B, D, c, nullptr, nullptr)));
+    }
+    return HSK_OK;
+  });
+  if (rc) return rc;
+  HSK_LAUNCH_CHECK();
+  HSK_STAGE(HSK_STAGE_FINISH, k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out,
+                                                                     st->global_bias, st->m_global_bias,
+                                                                     st->v_global_bias, c));
+  HSK_LAUNCH_CHECK();
+  if (st->lazy_users && (st->step % HSK_FLUSH_EVERY) == 0) {
+    int frc = 0;
+    HSK_STAGE(HSK_STAGE_USER, frc = hsk_launch_flush(st, w, stream));
+    if (frc) return frc;
+  }
+  return HSK_OK;
+}
+
+static int hsk_check_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols) {
+  HSK_REQUIRE(batch > 0 && batch <= st->max_batch, HSK_ERR_INVALID, "batch %lld outside (0, %lld]", (long long)batch,
+              (long long)st->max_batch);
+  HSK_REQUIRE(n_cols >= 2 && n_cols <= st->max_cols, HSK_ERR_INVALID, "n_cols %lld outside [2, %lld]",
+              (long long)n_cols, (long long)st->max_cols);
+  return HSK_OK;
+}
+
+extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, const int64_t* i_idx, int64_t batch,
+                                    int64_t n_cols, hsk_stream_t stream_) {
+  int rc = hsk_check_state(st);
+  if (rc) return rc;
+  HSK_REQUIRE(u_idx && i_idx, HSK_ERR_INVALID, "u_idx / i_idx must not be NULL");
+  if ((rc = hsk_check_batch(st, batch, n_cols))) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  const int64_t total = batch * n_cols;
+  HSK_STAGE(HSK_STAGE_PREP, k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
+                                u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, w.u32,
+                                w.it32, w.owner, w.cnt, st->status));
+  HSK_LAUNCH_CHECK();
+  return hsk_run_step(st, w, batch, n_cols, stream);
+}
+
+extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
+                                            int64_t n_neg, hsk_stream_t stream_) {
+  int rc = hsk_check_state(st);
+  if (rc) return rc;
+  HSK_REQUIRE(st->csr_indptr && st->csr_indices && st->coo_user && st->coo_item, HSK_ERR_INVALID,
+              "CSR/COO of the training interactions missing from the state");
+  if ((rc = hsk_check_batch(st, batch, n_neg + 1))) return rc;
+  HSK_REQUIRE(start >= 0 && start + batch <= st->nnz, HSK_ERR_INVALID, "interaction range [%lld, %lld) outside nnz %lld",
+              (long long)start, (long long)(start + batch), (long long)st->nnz);
+  hipStream_t stream = (hipStream_t)stream_;
+  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  // the RNG stream id is the index of the step about to be taken: every step draws fresh negatives
+  HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
+                                st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
+                                st->csr_indices, (int)st->n_items, st->seed, (uint64_t)st->step, w.u32, w.it32,
+                                w.owner, w.cnt, st->status));
+  HSK_LAUNCH_CHECK();
+  return hsk_run_step(st, w, batch, n_neg + 1, stream);
+}
+
+extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
+  int rc = hsk_check_state(st);
+  if (rc) return rc;
+  if (!st->lazy_users) return HSK_OK;  // dense user updates: nothing is pending
+  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  return hsk_launch_flush(st, w, (hipStream_t)stream_);
+}
+
+extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols, int64_t* u_out,
+                                    int64_t* i_out, hsk_stream_t stream_) {
+  int rc = hsk_check_state(st);
+  if (rc) return rc;
+  HSK_REQUIRE(u_out && i_out, HSK_ERR_INVALID, "output pointers must not be NULL");
+  if ((rc = hsk_check_batch(st, batch, n_cols))) return rc;
+  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  const int64_t total = batch * n_cols;
+  k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
+                                                                                      u_out, i_out);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+extern "C" int hsk_sample_negatives_uniform(const int64_t* csr_indptr, const int32_t* csr_indices, int64_t n_users,
+                                            int64_t n_items, const int64_t* u_idx, int64_t batch, int64_t n_neg,
+                                            uint64_t seed, uint64_t stream_id, int64_t* neg_out, int32_t* status,
+                                            hsk_stream_t stream_) {
+  HSK_REQUIRE(csr_indptr && csr_indices && u_idx && neg_out, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_users > 0 && n_items > 0 && n_items < 0x7fffffff && n_users < 0x7fffffff, HSK_ERR_INVALID,
+              "bad n_users / n_items");
+  HSK_REQUIRE(batch >= 0 && n_neg >= 1, HSK_ERR_INVALID, "bad batch / n_neg");
+  if (batch == 0) return HSK_OK;
+  k_sample_negatives<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, (hipStream_t)stream_>>>(
+      csr_indptr, csr_indices, (int)n_users, (int)n_items, u_idx, (int)batch, (int)n_neg, seed, stream_id, neg_out,
+      status);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}

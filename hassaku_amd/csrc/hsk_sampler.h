@@ -1,0 +1,122 @@
+// hsk_sampler.h -- batch preparation: int32 copies of a loader batch, or on-device batch construction with the
+// uniform rejection sampler (data/dataloader.py:56-57,92-129 of the reference), plus the per-user owner map.
+#pragma once
+#include "hsk_rows.h"
+
+// =============================================================================================
+// P0a: external batch -> int32 workspace copies, per-item histogram, per-user owner/count
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_prep_external(const int64_t* __restrict__ u_idx,
+                                                       const int64_t* __restrict__ i_idx, int B, int K,
+                                                       int n_users, int n_items, int* __restrict__ u32,
+                                                       int* __restrict__ it32,
+                                                       int* __restrict__ owner, int* __restrict__ cnt,
+                                                       int32_t* status) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * K;
+  if (e < total) {
+    const int it = hsk_clamp_index(i_idx[e], n_items, status);
+    it32[e] = it;
+  }
+  if (e < B) {
+    const int u = hsk_clamp_index(u_idx[e], n_users, status);
+    u32[e] = u;
+    atomicMin(&owner[u], (int)e);
+    atomicAdd(&cnt[u], 1);
+  }
+}
+
+// =============================================================================================
+// P0b: device batch construction + uniform rejection sampler (data/dataloader.py:92-129)
+// =============================================================================================
+__device__ __forceinline__ bool hsk_row_has(const int32_t* __restrict__ idx, long long lo, long long hi, int key) {
+  long long l = lo, h = hi;
+  while (l < h) {
+    const long long mid = (l + h) >> 1;
+    const int v = idx[mid];
+    if (v < key)
+      l = mid + 1;
+    else
+      h = mid;
+  }
+  return (l < hi) && (idx[l] == key);
+}
+
+// One draw for slot (b, n): Philox counter = (b, n, stream_lo, (stream_hi<<16) | block), 4 attempts per
+// block; exact uniform integer via Lemire's multiply-shift with rejection of the biased zone.
+__device__ __forceinline__ int hsk_draw_negative(const int32_t* __restrict__ csr_indices, long long row_lo,
+                                                 long long row_hi, uint32_t n_items, uint32_t b, uint32_t n,
+                                                 uint64_t seed, uint64_t stream_id, int32_t* status) {
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const uint32_t thresh = (uint32_t)(-(int32_t)n_items) % n_items;  // 2^32 mod n_items
+  int last = 0;
+  for (uint32_t blk = 0; blk < 4096u; ++blk) {
+    hsk_u32x4 ctr;
+    ctr.x = b;
+    ctr.y = n;
+    ctr.z = (uint32_t)stream_id;
+    ctr.w = ((uint32_t)(stream_id >> 32) << 16) | (blk & 0xffffu);
+    const hsk_u32x4 r = hsk_philox4x32_10(ctr, k0, k1);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const uint64_t m = (uint64_t)rr[a] * (uint64_t)n_items;
+      if ((uint32_t)m < thresh) continue;  // biased zone: costs one attempt
+      const int cand = (int)(m >> 32);
+      last = cand;
+      if (!hsk_row_has(csr_indices, row_lo, row_hi, cand)) return cand;
+    }
+  }
+  if (status) atomicOr(status, HSK_STATUS_SAMPLER_GAVE_UP);
+  return last;
+}
+
+// one wave per positive; lanes stride over the n_neg slots
+__global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__ coo_user,
+                                                     const int32_t* __restrict__ coo_item,
+                                                     const int64_t* __restrict__ order, long long start, int B,
+                                                     int n_neg, const int64_t* __restrict__ csr_indptr,
+                                                     const int32_t* __restrict__ csr_indices, int n_items,
+                                                     uint64_t seed, uint64_t stream_id, int* __restrict__ u32,
+                                                     int* __restrict__ it32,
+                                                     int* __restrict__ owner, int* __restrict__ cnt,
+                                                     int32_t* status) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const long long pos = order ? (long long)order[start + b] : (start + b);
+  const int u = coo_user[pos];
+  const int ipos = coo_item[pos];
+  const long long lo = csr_indptr[u], hi = csr_indptr[u + 1];
+  const int K = n_neg + 1;
+  int* row = it32 + (long long)b * K;
+  for (int n = lane; n < n_neg; n += 64) {
+    const int neg = hsk_draw_negative(csr_indices, lo, hi, (uint32_t)n_items, (uint32_t)b, (uint32_t)n, seed,
+                                      stream_id, status);
+    row[1 + n] = neg;
+  }
+  if (lane == 0) {
+    row[0] = ipos;
+    u32[b] = u;
+    atomicMin(&owner[u], b);
+    atomicAdd(&cnt[u], 1);
+  }
+}
+
+// stand-alone sampler on the int64 drop-in surface
+__global__ __launch_bounds__(256) void k_sample_negatives(const int64_t* __restrict__ csr_indptr,
+                                                          const int32_t* __restrict__ csr_indices, int n_users,
+                                                          int n_items, const int64_t* __restrict__ u_idx, int B,
+                                                          int n_neg, uint64_t seed, uint64_t stream_id,
+                                                          int64_t* __restrict__ out, int32_t* status) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int u = hsk_clamp_index(u_idx[b], n_users, status);
+  const long long lo = csr_indptr[u], hi = csr_indptr[u + 1];
+  for (int n = lane; n < n_neg; n += 64)
+    out[(long long)b * n_neg + n] = hsk_draw_negative(csr_indices, lo, hi, (uint32_t)n_items, (uint32_t)b,
+                                                      (uint32_t)n, seed, stream_id, status);
+}

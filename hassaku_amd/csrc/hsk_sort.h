@@ -1,0 +1,270 @@
+// hsk_sort.h -- deterministic, atomic-free grouping of the batch entries e = b*K + k by item id.
+//
+// The item-major gradient pass needs, per item, the list of entries that reference it.  A two-level
+// stable counting sort builds it (no global atomics, bitwise reproducible: inside an item the entries stay
+// in ascending e, so the fp32 summation order of an item-row gradient is a function of the batch only):
+//
+//   level 1  bucket = item >> shift (NB <= 512 buckets).  The entry range is cut into NU <= 512 wave-units
+//            of `epw` consecutive entries.
+//     k_sort_hist     per unit: histogram of its buckets in LDS           -> hist[bucket][unit]
+//     k_sort_rowscan  per bucket (one wave): exclusive scan over the units -> hist in place, btot[bucket]
+//     k_sort_scatter  bucket starts = scan of btot (every workgroup, in LDS); per unit, 64 entries at a time
+//                     in order: rank inside the chunk by a ballot "match-any", position = bucket start +
+//                     running base of (bucket, unit) + rank                 -> perm1, bstart
+//   level 2  k_sort_bucket: one workgroup per bucket, each wave owns a contiguous quarter of the bucket's
+//            entries: count per (wave, item), prefix, then the same ordered placement -> perm, offsets.
+// Every wave issues its index loads for 16 chunks (1024 entries) before it consumes them: these kernels are
+// latency-bound, not bandwidth-bound (the whole entry list is 1.6 MB at the ml10m shape).
+#pragma once
+#include "hsk_common.h"
+
+#define HSK_SORT_MAX_BUCKETS 512
+#define HSK_SORT_MAX_UNITS 512
+#define HSK_SORT_MAX_IPB 8192  // items per bucket the level-2 LDS counters can hold (5 x IPB ints <= 160 KB)
+#define HSK_SORT_GROUP 16      // chunks of 64 entries whose loads are issued together
+
+struct hsk_sort_plan {
+  int shift;      // bucket = item >> shift
+  int n_buckets;  // NB
+  int ipb;        // 1 << shift
+  int epw;        // entries per wave-unit (multiple of 1024)
+  int n_units;    // NU
+};
+
+static inline int hsk_make_sort_plan(int64_t n_items, int64_t n_entries, hsk_sort_plan* p) {
+  int shift = 0;
+  while (((n_items - 1) >> shift) + 1 > HSK_SORT_MAX_BUCKETS) ++shift;
+  p->shift = shift;
+  p->ipb = 1 << shift;
+  p->n_buckets = (int)(((n_items - 1) >> shift) + 1);
+  if (p->ipb > HSK_SORT_MAX_IPB) return -1;
+  int64_t epw = 1024;
+  while (hsk_ceil_div(n_entries, epw) > HSK_SORT_MAX_UNITS) epw *= 2;
+  p->epw = (int)epw;
+  p->n_units = (int)hsk_ceil_div(n_entries, epw);
+  return 0;
+}
+
+static inline int64_t hsk_sort_hist_elems(int64_t n_items, int64_t max_entries) {
+  hsk_sort_plan p;
+  if (hsk_make_sort_plan(n_items, max_entries, &p) != 0) return -1;
+  return (int64_t)p.n_buckets * HSK_SORT_MAX_UNITS;
+}
+
+#if defined(__HIPCC__)
+
+// lanes holding the same key as this lane (among `valid` lanes); keys < 2^nbits
+__device__ __forceinline__ unsigned long long hsk_match_any(int key, int nbits, bool valid) {
+  unsigned long long mask = __ballot(valid);
+  for (int bit = 0; bit < nbits; ++bit) {
+    const bool one = (key >> bit) & 1;
+    const unsigned long long bm = __ballot(one);
+    mask &= one ? bm : ~bm;
+  }
+  return mask;
+}
+
+__device__ __forceinline__ int hsk_bits_for(int n) {  // smallest nbits with 2^nbits >= n
+  int b = 0;
+  while ((1 << b) < n) ++b;
+  return b;
+}
+
+__device__ __forceinline__ int hsk_wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
+                                                   int* __restrict__ hist) {
+  __shared__ int cnt[4][HSK_SORT_MAX_BUCKETS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + w;
+  for (int d = lane; d < p.n_buckets; d += 64) cnt[w][d] = 0;
+  __syncthreads();
+  if (unit < p.n_units) {
+    const int lo = unit * p.epw, hi = min(n_entries, lo + p.epw);
+    for (int g0 = lo; g0 < hi; g0 += 64 * HSK_SORT_GROUP) {
+      int key[HSK_SORT_GROUP];
+#pragma unroll
+      for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+        const int e = g0 + j * 64 + lane;
+        key[j] = (e < hi) ? (it32[e] >> p.shift) : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < HSK_SORT_GROUP; ++j)
+        if (key[j] >= 0) atomicAdd(&cnt[w][key[j]], 1);
+    }
+  }
+  __syncthreads();
+  if (unit < p.n_units)
+    for (int d = lane; d < p.n_buckets; d += 64) hist[d * p.n_units + unit] = cnt[w][d];
+}
+
+// one wave per bucket: exclusive scan of hist[d][0..NU) in place, btot[d] = row total
+__global__ __launch_bounds__(256) void k_sort_rowscan(int* __restrict__ hist, hsk_sort_plan p, int* __restrict__ btot) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= p.n_buckets) return;
+  int* row = hist + (long long)d * p.n_units;
+  int v[HSK_SORT_MAX_UNITS / 64];
+#pragma unroll
+  for (int j = 0; j < HSK_SORT_MAX_UNITS / 64; ++j) {
+    const int u = j * 64 + lane;
+    v[j] = (u < p.n_units) ? row[u] : 0;
+  }
+  int carry = 0;
+#pragma unroll
+  for (int j = 0; j < HSK_SORT_MAX_UNITS / 64; ++j) {
+    const int u = j * 64 + lane;
+    const int incl = hsk_wave_incl_scan(v[j], lane);
+    if (u < p.n_units) row[u] = carry + incl - v[j];
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) btot[d] = carry;
+}
+
+// exclusive scan of btot[0..NB) into LDS bs[0..NB] by the calling workgroup's wave 0 (NB <= 512)
+__device__ __forceinline__ void hsk_bucket_starts(const int* __restrict__ btot, int nb, int* bs) {
+  const int lane = threadIdx.x & 63;
+  if ((threadIdx.x >> 6) == 0) {
+    int carry = 0;
+    for (int j0 = 0; j0 < nb; j0 += 64) {
+      const int j = j0 + lane;
+      const int v = (j < nb) ? btot[j] : 0;
+      const int incl = hsk_wave_incl_scan(v, lane);
+      if (j < nb) bs[j] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) bs[nb] = carry;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
+                                                      const int* __restrict__ hist, const int* __restrict__ btot,
+                                                      int2* __restrict__ perm1, int* __restrict__ bstart) {
+  __shared__ int run[4][HSK_SORT_MAX_BUCKETS];
+  __shared__ int bs[HSK_SORT_MAX_BUCKETS + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + w;
+  hsk_bucket_starts(btot, p.n_buckets, bs);
+  if (blockIdx.x == 0)
+    for (int d = threadIdx.x; d <= p.n_buckets; d += 256) bstart[d] = bs[d];
+  if (unit >= p.n_units) return;  // no barrier below: every wave works on its own LDS row
+  for (int d = lane; d < p.n_buckets; d += 64) run[w][d] = bs[d] + hist[d * p.n_units + unit];
+  __builtin_amdgcn_wave_barrier();
+  const int nbits = hsk_bits_for(p.n_buckets);
+  const int lo = unit * p.epw, hi = min(n_entries, lo + p.epw);
+  for (int g0 = lo; g0 < hi; g0 += 64 * HSK_SORT_GROUP) {
+    int itemv[HSK_SORT_GROUP];
+#pragma unroll
+    for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+      const int e = g0 + j * 64 + lane;
+      itemv[j] = (e < hi) ? it32[e] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+      if (g0 + j * 64 >= hi) break;  // wave-uniform
+      const bool valid = itemv[j] >= 0;
+      const int key = valid ? (itemv[j] >> p.shift) : 0;
+      const unsigned long long same = hsk_match_any(key, nbits, valid);
+      const int rank = __popcll(same & ((1ull << lane) - 1ull));
+      const int base = run[w][key];
+      if (valid) perm1[base + rank] = make_int2(g0 + j * 64 + lane, itemv[j]);  // (entry, item)
+      __builtin_amdgcn_wave_barrier();
+      if (valid && rank == 0) run[w][key] = base + __popcll(same);  // LDS ops of one wave execute in order
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ perm1, int n_entries, int n_items,
+                                                     hsk_sort_plan p, const int* __restrict__ bstart,
+                                                     int* __restrict__ perm, int* __restrict__ offsets) {
+  extern __shared__ int lds[];  // cnt[4][ipb] then tot[ipb]
+  const int ipb = p.ipb;
+  int* cnt = lds;
+  int* tot = lds + 4 * ipb;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.x;
+  const int beg = bstart[b], end = bstart[b + 1];
+  const int n = end - beg;
+  const int per = ((n + 3) / 4 + 63) / 64 * 64;  // entries per wave, multiple of 64 so chunks stay aligned
+  const int wlo = beg + min(n, w * per), whi = beg + min(n, (w + 1) * per);
+  const int item0 = b << p.shift;
+  // the first HSK_SORT_GROUP chunks of this wave stay in registers for both passes (the usual case: all of them)
+  int2 first[HSK_SORT_GROUP];
+#pragma unroll
+  for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+    const int q = wlo + j * 64 + lane;
+    first[j] = (q < whi) ? perm1[q] : make_int2(-1, -1);
+  }
+  for (int j = tid; j < 4 * ipb; j += 256) cnt[j] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < HSK_SORT_GROUP; ++j)
+    if (first[j].x >= 0) atomicAdd(&cnt[w * ipb + (first[j].y - item0)], 1);
+  for (int q = wlo + 64 * HSK_SORT_GROUP + lane; q < whi; q += 64) atomicAdd(&cnt[w * ipb + (perm1[q].y - item0)], 1);
+  __syncthreads();
+  // per item: total and per-wave exclusive bases (local, relative to the bucket start)
+  for (int j = tid; j < ipb; j += 256) {
+    const int c0 = cnt[j], c1 = cnt[ipb + j], c2 = cnt[2 * ipb + j], c3 = cnt[3 * ipb + j];
+    tot[j] = c0 + c1 + c2 + c3;
+    cnt[j] = 0;
+    cnt[ipb + j] = c0;
+    cnt[2 * ipb + j] = c0 + c1;
+    cnt[3 * ipb + j] = c0 + c1 + c2;
+  }
+  __syncthreads();
+  // exclusive scan of tot over the bucket's items (wave 0, sequential over chunks of 64)
+  if (w == 0) {
+    int carry = 0;
+    for (int j0 = 0; j0 < ipb; j0 += 64) {
+      const int j = j0 + lane;
+      const int v = (j < ipb) ? tot[j] : 0;
+      const int incl = hsk_wave_incl_scan(v, lane);
+      if (j < ipb) tot[j] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < ipb; j += 256) {
+    const int start = beg + tot[j];
+    if (item0 + j < n_items) offsets[item0 + j] = start;
+    cnt[j] += start;
+    cnt[ipb + j] += start;
+    cnt[2 * ipb + j] += start;
+    cnt[3 * ipb + j] += start;
+  }
+  if (b == p.n_buckets - 1 && tid == 0) offsets[n_items] = n_entries;
+  __syncthreads();
+  const int nbits = hsk_bits_for(ipb);
+  int* run = cnt + w * ipb;
+  auto place = [&](int2 ent) {   // one chunk of 64 entries, in order
+    const bool valid = ent.x >= 0;
+    const int key = valid ? (ent.y - item0) : 0;
+    const unsigned long long same = hsk_match_any(key, nbits, valid);
+    const int rank = __popcll(same & ((1ull << lane) - 1ull));
+    const int base = run[key];
+    if (valid) perm[base + rank] = ent.x;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) run[key] = base + __popcll(same);
+    __builtin_amdgcn_wave_barrier();
+  };
+#pragma unroll
+  for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+    if (wlo + j * 64 >= whi) break;  // wave-uniform
+    place(first[j]);
+  }
+  for (int c = wlo + 64 * HSK_SORT_GROUP; c < whi; c += 64) {
+    const int q = c + lane;
+    place((q < whi) ? perm1[q] : make_int2(-1, -1));
+  }
+}
+
+#endif  // __HIPCC__

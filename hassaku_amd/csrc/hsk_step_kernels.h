@@ -1,0 +1,466 @@
+// hsk_step_kernels.h -- the three heavy kernels of the fused BPR-MF step and its tail.
+#pragma once
+#include "hsk_rows.h"
+
+// =============================================================================================
+// K1: per positive b -- gather u row + (1+N) item rows, scores, BPR loss terms, d loss/d score,
+//     user-row gradient (accumulated in registers).  One wave per positive.
+//     reads:  4*D*(2+N) + 4*(1+N) + 4*(2+N) bytes per positive  (the "gather+BPR step" of SURVEY 8d)
+//     writes: g_s [B,1+N], dUb [B,D], loss_b [B]
+// =============================================================================================
+template <int V, int NCH, bool FULL, int R>
+__global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw, const float* __restrict__ Iw,
+                                                   const float* __restrict__ Ib, const int* __restrict__ u32,
+                                                   const int* __restrict__ it32, int B, int K, int D,
+                                                   float inv_bn, float* __restrict__ g_s,
+                                                   float* __restrict__ dUb, double* __restrict__ loss_b) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+
+  using Row = hsk_row<V, NCH>;
+  const int* __restrict__ irow = it32 + (long long)b * K;
+  const int u = hsk_uniform_i(u32[b]);
+  const int i0 = hsk_uniform_i(irow[0]);
+
+  Row ur, r0, acc;
+  hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
+  hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  hsk_row_zero(acc);
+  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
+
+  float gsum = 0.f;    // sum over negatives of sigma(-x)/(B*N)   (wave-uniform)
+  double lsum = 0.0;   // per-lane partial of sum softplus(-x)
+
+  for (int kc = 1; kc < K; kc += 64) {
+    const int nr = min(64, K - kc);
+    const int myidx = (lane < nr) ? irow[kc + lane] : i0;
+    const float mybias = Ib ? Ib[myidx] : 0.f;
+    float gv = 0.f, xv = 0.f;
+
+    Row bufA[R], bufB[R];
+    // prologue
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r < nr) hsk_row_load<V, NCH, FULL>(bufA[r], Iw + (long long)hsk_readlane_i(myidx, r) * D, lane, D);
+
+    auto process = [&](Row(&buf)[R], int j) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (j + r < nr) {
+          const float s = hsk_wave_sum(hsk_row_dot_partial(ur, buf[r])) + hsk_readlane_f(mybias, j + r);
+          const float x = s0 - s;
+          const float g = inv_bn / (1.f + expf(x));  // sigma(-x)/(B*N) = d loss / d s_neg
+          hsk_row_axpy(acc, g, buf[r]);
+          gsum += g;
+          gv = (lane == j + r) ? g : gv;
+          xv = (lane == j + r) ? x : xv;
+        }
+      }
+    };
+    auto prefetch = [&](Row(&buf)[R], int j) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (j + r < nr)
+          hsk_row_load<V, NCH, FULL>(buf[r], Iw + (long long)hsk_readlane_i(myidx, j + r) * D, lane, D);
+    };
+
+    for (int j = 0; j < nr; j += 2 * R) {
+      prefetch(bufB, j + R);
+      process(bufA, j);
+      prefetch(bufA, j + 2 * R);
+      process(bufB, j + R);
+    }
+    if (lane < nr) {
+      g_s[(long long)b * K + kc + lane] = gv;
+      lsum += (double)hsk_softplus(-xv);
+    }
+  }
+  // positive: d loss / d s_pos = -sum_n sigma(-x_n)/(B*N)
+  const float g0 = -gsum;
+  hsk_row_axpy(acc, g0, r0);
+  if (lane == 0) g_s[(long long)b * K] = g0;
+  hsk_row_store<V, NCH, FULL>(acc, dUb + (long long)b * D, lane, D);
+  const double l = hsk_wave_sum_f64(lsum);
+  if (lane == 0) loss_b[b] = l;
+}
+
+// =============================================================================================
+// K2: per item i -- reduce the gradient of row i over its (b,k) occurrences (item-major list built
+//     by P0-P2), then apply AdamW to the row in the same wave (dense semantics: untouched rows get
+//     the zero-gradient update).  One wave per item.  APPLY=false writes the dense gradient instead.
+// =============================================================================================
+template <int V, int NCH, bool FULL, int R, bool APPLY>
+__global__ __launch_bounds__(256) void k_item_update(const float* __restrict__ Uw, float* __restrict__ Iw,
+                                                     float* __restrict__ Ib, float* __restrict__ mI,
+                                                     float* __restrict__ vI, float* __restrict__ mIb,
+                                                     float* __restrict__ vIb, const int* __restrict__ u32,
+                                                     const float* __restrict__ g_s, const int* __restrict__ perm,
+                                                     const int* __restrict__ offsets,
+                                                     int n_items, int K, int D, hsk_adamw_consts c,
+                                                     float* __restrict__ gI_out, float* __restrict__ gIb_out) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n_items) return;
+  using Row = hsk_row<V, NCH>;
+
+  const int beg = hsk_uniform_i(offsets[i]);
+  const int end = hsk_uniform_i(offsets[i + 1]);
+  Row acc;
+  hsk_row_zero(acc);
+  float gb_lane = 0.f;
+
+  for (int c0 = beg; c0 < end; c0 += 64) {
+    const int nr = min(64, end - c0);
+    int myu = 0;
+    float myg = 0.f;
+    if (lane < nr) {
+      const int e = perm[c0 + lane];
+      myg = g_s[e];
+      myu = u32[e / K];
+    }
+    gb_lane += myg;
+
+    Row bufA[R], bufB[R];
+    auto prefetch = [&](Row(&buf)[R], int j) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (j + r < nr)
+          hsk_row_load<V, NCH, FULL>(buf[r], Uw + (long long)hsk_readlane_i(myu, j + r) * D, lane, D);
+    };
+    auto process = [&](Row(&buf)[R], int j) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (j + r < nr) hsk_row_axpy(acc, hsk_readlane_f(myg, j + r), buf[r]);
+    };
+    prefetch(bufA, 0);
+    for (int j = 0; j < nr; j += 2 * R) {
+      prefetch(bufB, j + R);
+      process(bufA, j);
+      prefetch(bufA, j + 2 * R);
+      process(bufB, j + R);
+    }
+  }
+  const float gbias = hsk_wave_sum(gb_lane);
+
+  if (APPLY) {
+    float* prow = Iw + (long long)i * D;
+    float* mrow = mI + (long long)i * D;
+    float* vrow = vI + (long long)i * D;
+    Row p, m, v;
+    hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+    hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+    hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int q = 0; q < V; ++q) hsk_adamw_update(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], acc.c[cc].v[q], c);
+    hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+    hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+    hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+    if (lane == 0) {
+      if (Ib) {
+        float pb = Ib[i], mb = mIb[i], vb = vIb[i];
+        hsk_adamw_update(pb, mb, vb, gbias, c);
+        Ib[i] = pb;
+        mIb[i] = mb;
+        vIb[i] = vb;
+      }
+    }
+  } else {
+    hsk_row_store<V, NCH, FULL>(acc, gI_out + (long long)i * D, lane, D);
+    if (lane == 0) {
+      if (gIb_out) gIb_out[i] = gbias;
+    }
+  }
+}
+
+// =============================================================================================
+// K3: user rows.  Row gradient = sum of dUb[b] over the batch entries with u32[b] == row, added in
+//     ascending b (deterministic).  owner[row] = min b, cnt[row] = multiplicity (from P0).
+//     MODE 0: dense AdamW sweep over all rows (one wave per table row)
+//     MODE 1: dense gradient output (compat backward)
+// =============================================================================================
+template <int V, int NCH, bool FULL>
+__device__ __forceinline__ void hsk_user_grad(hsk_row<V, NCH>& acc, float& gbias_unused, int row, int b0, int c,
+                                              const float* __restrict__ dUb, const int* __restrict__ u32, int B,
+                                              int D, int lane) {
+  hsk_row_load<V, NCH, FULL>(acc, dUb + (long long)b0 * D, lane, D);
+  if (c > 1) {
+    for (int c0 = (b0 / 64) * 64; c0 < B; c0 += 64) {
+      const int bb = c0 + lane;
+      const bool match = (bb < B) && (bb > b0) && (u32[bb] == row);
+      unsigned long long mask = __ballot(match);
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        hsk_row<V, NCH> t;
+        hsk_row_load<V, NCH, FULL>(t, dUb + (long long)(c0 + j) * D, lane, D);
+        hsk_row_add(acc, t);
+      }
+    }
+  }
+}
+
+template <int V, int NCH, bool FULL, int MODE>
+__global__ __launch_bounds__(256) void k_user_update(float* __restrict__ Uw, float* __restrict__ mU,
+                                                     float* __restrict__ vU, float* __restrict__ Ub,
+                                                     float* __restrict__ mUb, float* __restrict__ vUb,
+                                                     const float* __restrict__ dUb, const int* __restrict__ u32,
+                                                     int* __restrict__ owner, int* __restrict__ cnt, int n_users,
+                                                     int B, int D, hsk_adamw_consts c,
+                                                     float* __restrict__ gU_out, float* __restrict__ gUb_out) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= n_users) return;
+  using Row = hsk_row<V, NCH>;
+  const int n = hsk_uniform_i(cnt[row]);
+  Row g;
+  float dummy = 0.f;
+  if (n > 0) {
+    const int b0 = hsk_uniform_i(owner[row]);
+    hsk_user_grad<V, NCH, FULL>(g, dummy, row, b0, n, dUb, u32, B, D, lane);
+    if (lane == 0) {
+      owner[row] = HSK_OWNER_NONE;
+      cnt[row] = 0;
+    }
+  } else {
+    hsk_row_zero(g);
+  }
+  if (MODE == 0) {
+    float* prow = Uw + (long long)row * D;
+    float* mrow = mU + (long long)row * D;
+    float* vrow = vU + (long long)row * D;
+    Row p, m, v;
+    hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+    hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+    hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int q = 0; q < V; ++q) hsk_adamw_update(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], c);
+    hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+    hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+    hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+    if (Ub && lane == 0) {
+      // d loss / d user_bias is identically 0 under BPR (it cancels in s_pos - s_neg)
+      float pb = Ub[row], mb = mUb[row], vb = vUb[row];
+      hsk_adamw_update(pb, mb, vb, 0.f, c);
+      Ub[row] = pb;
+      mUb[row] = mb;
+      vUb[row] = vb;
+    }
+  } else {
+    hsk_row_store<V, NCH, FULL>(g, gU_out + (long long)row * D, lane, D);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lazy, exact user-table AdamW.  torch.optim.AdamW updates EVERY row each step; a row outside the batch
+// sees g = 0: p *= decay; m *= b1 (as lerp); v *= b2; p -= ss_t * m / (sqrt(v)/bc2s_t + eps).  That
+// recurrence needs nothing but the row itself and the per-step scalars (ss_t, bc2s_t), so it can be
+// replayed later: last_step[row] = number of steps already applied; when the row is next touched (or at a
+// flush) the missed steps are replayed in registers with the same fp32 operations the dense sweep would
+// have executed -- results are bit-identical to the dense sweep, HBM traffic is only the touched rows.
+// tab[t] = (ss_t, bc2s_t) for t in [1, tab_len]; for t > tab_len the entry tab_len applies (both saturated).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ hsk_adamw_consts hsk_consts_at(const hsk_adamw_consts& base, const float2* __restrict__ tab,
+                                                          int tab_len, int t) {
+  hsk_adamw_consts c = base;
+  const float2 e = tab[min(t, tab_len)];   // (step_size, bc2_sqrt or its reciprocal, see hsk_fused.hip)
+  c.step_size = e.x;
+#if HSK_ADAM_IEEE
+  c.bc2_sqrt = e.y;
+#else
+  c.rbc2_sqrt = e.y;
+#endif
+  return c;
+}
+
+template <int V, int NCH, bool FULL>
+__device__ __forceinline__ void hsk_row_catch_up(hsk_row<V, NCH>& p, hsk_row<V, NCH>& m, hsk_row<V, NCH>& v, int from,
+                                                 int to, const hsk_adamw_consts& base,
+                                                 const float2* __restrict__ tab, int tab_len) {
+  // zero-gradient steps from+1 .. to (wave-uniform trip count)
+  for (int t = from + 1; t <= to; ++t) {
+    const hsk_adamw_consts c = hsk_consts_at(base, tab, tab_len, t);
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int q = 0; q < V; ++q) hsk_adamw_update(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], 0.f, c);
+  }
+}
+
+// Lazy mode, before the forward: one wave per batch entry, the owner (lowest b) of each distinct user brings
+// that user's row up to step-1, so the gather/score kernels read current parameters.
+template <int V, int NCH, bool FULL>
+__global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, float* __restrict__ mU,
+                                                       float* __restrict__ vU, float* __restrict__ Ub,
+                                                       float* __restrict__ mUb, float* __restrict__ vUb,
+                                                       const int* __restrict__ u32, const int* __restrict__ owner,
+                                                       int* __restrict__ last_step, int B, int D, int step,
+                                                       hsk_adamw_consts c, const float2* __restrict__ tab,
+                                                       int tab_len) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int row = hsk_uniform_i(u32[b]);
+  if (hsk_uniform_i(owner[row]) != b) return;
+  const int done = hsk_uniform_i(last_step[row]);
+  if (done >= step - 1) return;
+  using Row = hsk_row<V, NCH>;
+  float* prow = Uw + (long long)row * D;
+  float* mrow = mU + (long long)row * D;
+  float* vrow = vU + (long long)row * D;
+  Row p, m, v;
+  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  hsk_row_catch_up<V, NCH, FULL>(p, m, v, done, step - 1, c, tab, tab_len);
+  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  if (lane == 0) {
+    if (Ub) {
+      float pb = Ub[row], mb = mUb[row], vb = vUb[row];
+      for (int t = done + 1; t <= step - 1; ++t) hsk_adamw_update(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
+      Ub[row] = pb;
+      mUb[row] = mb;
+      vUb[row] = vb;
+    }
+    last_step[row] = step - 1;
+  }
+}
+
+// Lazy mode, after the gradients: the owner applies step `step` to its (already current) row.
+template <int V, int NCH, bool FULL>
+__global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw, float* __restrict__ mU,
+                                                          float* __restrict__ vU, float* __restrict__ Ub,
+                                                          float* __restrict__ mUb, float* __restrict__ vUb,
+                                                          const float* __restrict__ dUb, const int* __restrict__ u32,
+                                                          int* __restrict__ owner, int* __restrict__ cnt,
+                                                          int* __restrict__ last_step, int B, int D, int step,
+                                                          hsk_adamw_consts c) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int row = hsk_uniform_i(u32[b]);
+  if (hsk_uniform_i(owner[row]) != b) return;
+  using Row = hsk_row<V, NCH>;
+  const int n = hsk_uniform_i(cnt[row]);
+  Row g;
+  float dummy = 0.f;
+  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, dUb, u32, B, D, lane);
+  float* prow = Uw + (long long)row * D;
+  float* mrow = mU + (long long)row * D;
+  float* vrow = vU + (long long)row * D;
+  Row p, m, v;
+  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+#pragma unroll
+  for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+    for (int q = 0; q < V; ++q) hsk_adamw_update(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], c);
+  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  if (lane == 0) {
+    if (Ub) {
+      float pb = Ub[row], mb = mUb[row], vb = vUb[row];
+      hsk_adamw_update(pb, mb, vb, 0.f, c);
+      Ub[row] = pb;
+      mUb[row] = mb;
+      vUb[row] = vb;
+    }
+    last_step[row] = step;
+    // last reader of the owner map this step; a duplicate entry that reads NONE afterwards just exits
+    owner[row] = HSK_OWNER_NONE;
+    cnt[row] = 0;
+  }
+}
+
+// bring every row with last_step < step up to `step` (one wave per table row)
+template <int V, int NCH, bool FULL>
+__global__ __launch_bounds__(256) void k_user_flush(float* __restrict__ Uw, float* __restrict__ mU,
+                                                    float* __restrict__ vU, float* __restrict__ Ub,
+                                                    float* __restrict__ mUb, float* __restrict__ vUb,
+                                                    int* __restrict__ last_step, int n_users, int D, int step,
+                                                    hsk_adamw_consts c, const float2* __restrict__ tab, int tab_len) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= n_users) return;
+  const int done = hsk_uniform_i(last_step[row]);
+  if (done >= step) return;
+  using Row = hsk_row<V, NCH>;
+  float* prow = Uw + (long long)row * D;
+  float* mrow = mU + (long long)row * D;
+  float* vrow = vU + (long long)row * D;
+  Row p, m, v;
+  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  hsk_row_catch_up<V, NCH, FULL>(p, m, v, done, step, c, tab, tab_len);
+  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  if (lane == 0) {
+    if (Ub) {
+      float pb = Ub[row], mb = mUb[row], vb = vUb[row];
+      for (int t = done + 1; t <= step; ++t) hsk_adamw_update(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
+      Ub[row] = pb;
+      mUb[row] = mb;
+      vUb[row] = vb;
+    }
+    last_step[row] = step;
+  }
+}
+
+// tail: deterministic fp64 reduction of the per-positive loss sums; global-bias zero-grad AdamW step
+__global__ __launch_bounds__(1024) void k_finish_step(const double* __restrict__ loss_b, int B, double inv_bn,
+                                                      double* __restrict__ loss_out, float* gb, float* mgb,
+                                                      float* vgb, hsk_adamw_consts c) {
+  __shared__ double red[1024];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int i = t; i < B; i += 1024) s += loss_b[i];
+  red[t] = s;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) {
+    if (t < off) red[t] += red[t + off];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double loss = red[0] * inv_bn;
+    if (loss_out) {
+      loss_out[0] = loss;
+      loss_out[1] += loss;
+    }
+    if (gb) {
+      float p = gb[0], m = mgb[0], v = vgb[0];
+      hsk_adamw_update(p, m, v, 0.f, c);
+      gb[0] = p;
+      mgb[0] = m;
+      vgb[0] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_i32(int* p, long long n, int v) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_widen_batch(const int* __restrict__ u32, const int* __restrict__ it32,
+                                                     long long B, long long total, int64_t* __restrict__ u_out,
+                                                     int64_t* __restrict__ i_out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total) i_out[e] = it32[e];
+  if (e < B) u_out[e] = u32[e];
+}

@@ -167,7 +167,7 @@ class BprMfFusedState:
 
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, seed=0,
-                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None):
+                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True):
         _lib.require_gpu()
         self.lib = _lib.load()
         n_users, dim = user_emb.shape
@@ -213,7 +213,8 @@ class BprMfFusedState:
         st.seed = seed & 0xFFFFFFFFFFFFFFFF
         st.workspace, st.workspace_bytes = _p(self.workspace), nbytes
         st.max_batch, st.max_cols = self.max_batch, self.max_cols
-        st.lazy_users = 0
+        # exact lazy AdamW on user rows (bit-identical to the dense sweep after flush()); dense when False
+        st.lazy_users = 1 if lazy_users else 0
         st.timing_mask = 0
         st.timing = None
         self._timing = None

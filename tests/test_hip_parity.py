@@ -95,6 +95,7 @@ def test_fused_step_three_steps_vs_golden(ops, case):
     st, t = _fused_state(ops, P, float(fx['lr']), float(fx['wd']), B, K)
     for step in (1, 2, 3):
         st.step(dev(fx[f's{step}.u_idx']), dev(fx[f's{step}.i_idx']))
+        st.flush()   # lazy user rows -> current (bit-identical to the dense sweep)
         loss = st.last_loss()
         assert abs(loss - float(fx[f's{step}.loss'])) <= 1e-6 * float(fx[f's{step}.loss']), step
         if step in (1, 3):
@@ -123,6 +124,7 @@ def test_fused_step_zero_grad_biases_only_decay(ops):
     st, t = _fused_state(ops, P, lr, wd, B, K)
     for step in (1, 2, 3):
         st.step(dev(fx[f's{step}.u_idx']), dev(fx[f's{step}.i_idx']))
+    st.flush()
     d = np.float32(1.0 - lr * wd)
     exp_ub = P['user_bias'].reshape(-1) * d * d * d
     np.testing.assert_allclose(t['user_bias'].cpu().numpy(), exp_ub, rtol=1e-6)
@@ -147,6 +149,7 @@ def test_fused_replay_of_reference_fit(ops, oracle):
         if s == spe - 1:
             ep_loss = st.pop_loss_sum() / spe
             assert 0.6 < ep_loss < 0.7
+    st.flush()
     assert_adam_param_close(t['user_emb'].cpu().numpy(), fx['final.user_embeddings.weight'], '')
     assert_adam_param_close(t['item_emb'].cpu().numpy(), fx['final.item_embeddings.weight'], '')
     assert_adam_param_close(t['item_bias'].cpu().numpy(), fx['final.item_bias.weight'].reshape(-1), '')
@@ -170,6 +173,7 @@ def test_fused_step_vs_oracle_random_shapes(ops, oracle, D, U, I, B, N):
         st.step(dev(u), dev(i))
         loss_ref, _, _, _ = tr.step(u, i)
         assert abs(st.last_loss() - loss_ref) <= 1e-6 * loss_ref
+    st.flush()
     for name in P:
         assert_adam_param_close(st.m[name].cpu().numpy(), tr.M[name], ('m', name))
         assert_adam_param_close(st.v[name].cpu().numpy(), tr.V[name], ('v', name))
@@ -192,6 +196,48 @@ def test_cpu_tensors_are_refused(ops):
     with pytest.raises(RuntimeError):
         ops.mf_scores(torch.randn(4, 8), torch.randn(4, 8), None, None, None, torch.zeros(1, dtype=torch.int64),
                       torch.zeros((1, 2), dtype=torch.int64))
+
+
+def _run_random_steps(ops, n_steps, lazy, seed=5, U=300, I=200, D=64, B=48, N=9, bias=True):
+    rng = np.random.RandomState(seed)
+    P = {'user_emb': (rng.randn(U, D) * 0.05).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(I) * 0.1).astype(np.float32)}
+    if bias:
+        P['user_bias'] = (rng.randn(U) * 0.1).astype(np.float32)
+        P['global_bias'] = np.array([0.3], np.float32)
+    st, t = _fused_state(ops, P, 2e-3, 1e-4, B, N + 1, lazy_users=lazy)
+    losses = []
+    for s in range(n_steps):
+        u = rng.randint(0, U, size=B).astype(np.int64)
+        u[:6] = u[6:12]                      # duplicate users inside the batch
+        i = rng.randint(0, I, size=(B, N + 1)).astype(np.int64)
+        st.step(dev(u), dev(i))
+        if s % 10 == 0:
+            losses.append(st.last_loss())
+    st.flush()
+    out = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    out.update({'m.' + k: v.cpu().numpy().copy() for k, v in st.m.items() if v is not None})
+    out.update({'v.' + k: v.cpu().numpy().copy() for k, v in st.v.items() if v is not None})
+    st.check_status()
+    return out, losses
+
+
+def test_lazy_user_adamw_is_bitwise_the_dense_sweep(ops):
+    """Exact lazy catch-up == dense AdamW on every user row, across the periodic flush (step 64) boundary."""
+    dense, l0 = _run_random_steps(ops, 150, lazy=False)
+    lazy, l1 = _run_random_steps(ops, 150, lazy=True)
+    assert l0 == l1
+    for k in dense:
+        assert np.array_equal(dense[k], lazy[k]), k
+
+
+def test_fused_step_is_bitwise_reproducible(ops):
+    """No atomics on the data path: two runs of the same batches give identical bits."""
+    a, la = _run_random_steps(ops, 40, lazy=True, seed=9, U=80, I=37, B=64, N=30)   # ~50 entries per item
+    b, lb = _run_random_steps(ops, 40, lazy=True, seed=9, U=80, I=37, B=64, N=30)
+    assert la == lb
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -283,6 +329,7 @@ def test_fused_sampled_step_matches_oracle_on_its_own_batch(ops, oracle):
         prev = i[:40, 1:].copy()
         loss_ref, _, _, _ = tr.step(u, i)
         assert abs(st.last_loss() - loss_ref) <= 1e-6 * loss_ref
+    st.flush()
     for name in P:
         assert_adam_param_close(t[name].cpu().numpy(), tr.P[name], name)
     st.check_status()
@@ -400,6 +447,7 @@ def test_full_size_properties_cfg3(ops):
     loss_unfused, _ = ops.bpr_loss_grad(logits, need_grad=False)
     before_u = P['user_emb'][:64].clone()
     st.step(u, i)
+    st.flush()
     assert abs(st.last_loss() - loss_unfused.item()) <= 1e-6 * loss_unfused.item()
     assert torch.isfinite(P['user_emb']).all() and torch.isfinite(P['item_emb']).all()
     touched = torch.zeros(U, dtype=torch.bool, device='cuda')
