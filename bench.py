@@ -44,7 +44,7 @@ def fwd_read_bytes(B, N, D):
     return 4 * D * B * (2 + N) + 4 * B * (1 + N) + 4 * B * (1 + N) + 4 * B
 
 
-def build_state(data, D, B, N, device, seed=64):
+def build_state(data, D, B, N, device, seed=64, **kw):
     from hassaku_amd import hip_ops as ops
     from hassaku_amd.data.csr import UserItemCsr
     U, I = data.n_users, data.n_items
@@ -57,7 +57,7 @@ def build_state(data, D, B, N, device, seed=64):
     coo_u = torch.from_numpy(data.train[:, 0].astype(np.int32)).to(device)
     coo_i = torch.from_numpy(data.train[:, 1].astype(np.int32)).to(device)
     st = ops.BprMfFusedState(user_emb, item_emb, item_bias, lr=LR, wd=WD, max_batch=B, max_cols=N + 1, seed=seed,
-                             csr_indptr=indptr, csr_indices=indices, coo_user=coo_u, coo_item=coo_i)
+                             csr_indptr=indptr, csr_indices=indices, coo_user=coo_u, coo_item=coo_i, **kw)
     return st, csr
 
 
@@ -92,6 +92,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='ml10m', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU-baseline work (0 = skip)')
+    ap.add_argument('--overlap', action='store_true', help='item sort + loss reduction on a side stream')
+    ap.add_argument('--dense-users', action='store_true', help='dense AdamW sweep over the user table every step')
     ap.add_argument('--time-all-stages', action='store_true', help='event-time every stage (perturbs the step time)')
     args = ap.parse_args()
 
@@ -112,7 +114,7 @@ def main():
     from hassaku_amd.data import synthetic
     shape, D, N, B = WORKLOADS[args.workload]
     data = synthetic.generate_named(shape, seed=0)
-    st, csr = build_state(data, D, B, N, device)
+    st, csr = build_state(data, D, B, N, device, overlap=args.overlap, lazy_users=not args.dense_users)
     nnz = data.train.shape[0]
     if world > 1:
         raise SystemExit('multi-GPU bench: not wired in this build')
@@ -129,7 +131,9 @@ def main():
     run(args.warmup, 0)
     torch.cuda.synchronize()
     st.check_status('warm-up')
-    st.enable_timing(st.STAGES if args.time_all_stages else ('fwd',))
+    # every stage on every step when asked; otherwise only the roofline kernel, on every 8th step, so that the
+    # event records (each costs a few us of launch gap) do not distort the step time being measured
+    st.enable_timing(st.STAGES if args.time_all_stages else ('fwd',), every=1 if args.time_all_stages else 8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps, args.warmup)

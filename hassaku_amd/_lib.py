@@ -33,7 +33,8 @@ class HskBprmfState(ctypes.Structure):
         ('workspace', c_void_p), ('workspace_bytes', c_int64),
         ('max_batch', c_int64), ('max_cols', c_int64),
         ('lazy_users', c_int32), ('timing_mask', c_int32),
-        ('timing', c_void_p),
+        ('timing', c_void_p), ('aux', c_void_p),
+        ('timing_every', c_int32), ('timing_now', c_int32),
         ('loss_out', c_void_p), ('status', c_void_p),
     ]
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     'hsk_timing_create': (c_void_p, []),
     'hsk_timing_destroy': (None, [c_void_p]),
     'hsk_timing_collect': (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    'hsk_aux_create': (c_void_p, []),
+    'hsk_aux_destroy': (None, [c_void_p]),
     'hsk_bprmf_flush': (c_int, [POINTER(HskBprmfState), c_void_p]),
     'hsk_bprmf_last_batch': (c_int, [POINTER(HskBprmfState), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'hsk_mf_eval_topk': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,

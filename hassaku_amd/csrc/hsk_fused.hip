@@ -198,7 +198,7 @@ extern "C" int hsk_timing_collect(void* t_, double* ms_sum, int64_t* count) {
 
 static inline void hsk_stage_mark(const hsk_bprmf_state* st, int stage, bool begin, hipStream_t stream) {
   hsk_timing* t = (hsk_timing*)st->timing;
-  if (!t || !((st->timing_mask >> stage) & 1)) return;
+  if (!t || !st->timing_now || !((st->timing_mask >> stage) & 1)) return;
   hipEvent_t e = t->get();
   if (!e) return;
   (void)hipEventRecord(e, stream);
@@ -212,6 +212,40 @@ static inline void hsk_stage_mark(const hsk_bprmf_state* st, int stage, bool beg
     hsk_stage_mark(st, (stage), false, stream);    \
   } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// aux handle: a side stream + events so that independent stages of one step overlap
+// ---------------------------------------------------------------------------------------------
+struct hsk_aux {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_fwd = nullptr, ev_join = nullptr;
+};
+
+extern "C" void hsk_aux_destroy(void* a_) {
+  hsk_aux* a = (hsk_aux*)a_;
+  if (!a) return;
+  if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
+  if (a->ev_sorted) (void)hipEventDestroy(a->ev_sorted);
+  if (a->ev_fwd) (void)hipEventDestroy(a->ev_fwd);
+  if (a->ev_join) (void)hipEventDestroy(a->ev_join);
+  if (a->side) (void)hipStreamDestroy(a->side);
+  delete a;
+}
+
+extern "C" void* hsk_aux_create(void) {
+  hsk_aux* a = new hsk_aux();
+  bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->ev_sorted, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->ev_fwd, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    hsk_set_error("hsk_aux_create: could not create the side stream / events");
+    hsk_aux_destroy(a);
+    return nullptr;
+  }
+  return a;
+}
+
 // =============================================================================================
 // launch sequence
 // =============================================================================================
@@ -219,15 +253,15 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
   const int U = (int)st->n_users, D = (int)st->dim;
   if (st->step == 0) return HSK_OK;
   const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
-  int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
-    constexpr int V = decltype(v_)::value;
-    constexpr int NCH = decltype(n_)::value;
-    constexpr bool FULL = decltype(f_)::value;
-    k_user_flush<V, NCH, FULL><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
-        st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias, st->v_user_bias, w.last_step, U,
-        D, (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN);
-    return HSK_OK;
-  });
+  if (D % 2 == 0)
+    k_user_flush<2><<<(unsigned)U, 256, 0, stream>>>(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias,
+                                                     st->m_user_bias, st->v_user_bias, w.last_step, U, D, (int)st->step,
+                                                     c, w.adam_tab, HSK_ADAM_TAB_LEN);
+  else
+    k_user_flush<1><<<(unsigned)U, 256, 0, stream>>>(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias,
+                                                     st->m_user_bias, st->v_user_bias, w.last_step, U, D, (int)st->step,
+                                                     c, w.adam_tab, HSK_ADAM_TAB_LEN);
+  int rc = 0;
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
   return HSK_OK;
@@ -247,18 +281,30 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
   const size_t bucket_lds = (size_t)5 * plan.ipb * sizeof(int);
   if (bucket_lds > 65536)
     HSK_HIP(hipFuncSetAttribute((const void*)k_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds));
-  HSK_STAGE(HSK_STAGE_SCAN, {
-    k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist);
-    k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
-  });
-  HSK_LAUNCH_CHECK();
-  HSK_STAGE(HSK_STAGE_SCATTER, {
-    k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist,
-                                                                                 w.btot, w.perm1, w.bstart);
-    k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(w.perm1, (int)total, I, plan, w.bstart, w.perm,
-                                                                         w.offsets);
-  });
-  HSK_LAUNCH_CHECK();
+  // The item sort only depends on prep and is only needed by k_item_update: with an aux handle it runs on the
+  // side stream, concurrently with the catch-up and the forward kernel (fork/join by events, capturable).
+  hsk_aux* aux = (hsk_aux*)st->aux;
+  hipStream_t main_stream = stream;
+  if (aux) {
+    HSK_HIP(hipEventRecord(aux->ev_fork, main_stream));
+    HSK_HIP(hipStreamWaitEvent(aux->side, aux->ev_fork, 0));
+  }
+  {
+    hipStream_t stream = aux ? aux->side : main_stream;
+    HSK_STAGE(HSK_STAGE_SCAN, {
+      k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist);
+      k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
+    });
+    HSK_LAUNCH_CHECK();
+    HSK_STAGE(HSK_STAGE_SCATTER, {
+      k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist,
+                                                                                   w.btot, w.perm1, w.bstart);
+      k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(w.perm1, (int)total, I, plan, w.bstart,
+                                                                           w.perm, w.offsets);
+    });
+    HSK_LAUNCH_CHECK();
+    if (aux) HSK_HIP(hipEventRecord(aux->ev_sorted, stream));
+  }
 
   int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
     constexpr int V = decltype(v_)::value;
@@ -267,14 +313,27 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
     if (st->lazy_users) {
       // the forward must read current rows: replay the missed zero-gradient steps of this batch's users first
-      HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<V, NCH, FULL><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
-                                    st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
-                                    st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,
-                                    w.adam_tab, HSK_ADAM_TAB_LEN)));
+      if (D % 2 == 0) {
+        HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<2><<<(unsigned)B, 256, 0, stream>>>(
+                                      st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
+                                      st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,
+                                      w.adam_tab, HSK_ADAM_TAB_LEN)));
+      } else {
+        HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<1><<<(unsigned)B, 256, 0, stream>>>(
+                                      st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
+                                      st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,
+                                      w.adam_tab, HSK_ADAM_TAB_LEN)));
+      }
     }
     HSK_STAGE(HSK_STAGE_FWD, (k_fwd_ugrad<V, NCH, FULL, R><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
                                  st->user_emb, st->item_emb, st->item_bias, w.u32, w.it32, (int)B, (int)K, D, inv_bn,
                                  w.g_s, w.dUb, w.loss_b)));
+    if (aux) {
+      // side stream: loss reduction + global bias as soon as the forward is done; main: join the sort
+      (void)hipEventRecord(aux->ev_fwd, stream);
+      (void)hipStreamWaitEvent(aux->side, aux->ev_fwd, 0);
+      (void)hipStreamWaitEvent(stream, aux->ev_sorted, 0);
+    }
     HSK_STAGE(HSK_STAGE_ITEM, (k_item_update<V, NCH, FULL, R, true><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
                                   st->user_emb, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb,
                                   st->m_item_bias, st->v_item_bias, w.u32, w.g_s, w.perm, w.offsets, I, (int)K, D, c,
@@ -293,10 +352,17 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
   });
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
-  HSK_STAGE(HSK_STAGE_FINISH, k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out,
-                                                                     st->global_bias, st->m_global_bias,
-                                                                     st->v_global_bias, c));
-  HSK_LAUNCH_CHECK();
+  {
+    hipStream_t stream = aux ? aux->side : main_stream;
+    HSK_STAGE(HSK_STAGE_FINISH, k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out,
+                                                                       st->global_bias, st->m_global_bias,
+                                                                       st->v_global_bias, c));
+    HSK_LAUNCH_CHECK();
+    if (aux) {
+      HSK_HIP(hipEventRecord(aux->ev_join, stream));
+      HSK_HIP(hipStreamWaitEvent(main_stream, aux->ev_join, 0));
+    }
+  }
   if (st->lazy_users && (st->step % HSK_FLUSH_EVERY) == 0) {
     int frc = 0;
     HSK_STAGE(HSK_STAGE_USER, frc = hsk_launch_flush(st, w, stream));
@@ -322,6 +388,7 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   hipStream_t stream = (hipStream_t)stream_;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   const int64_t total = batch * n_cols;
+  st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
   HSK_STAGE(HSK_STAGE_PREP, k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
                                 u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, w.u32,
                                 w.it32, w.owner, w.cnt, st->status));
@@ -341,6 +408,7 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   hipStream_t stream = (hipStream_t)stream_;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   // the RNG stream id is the index of the step about to be taken: every step draws fresh negatives
+  st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
   HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
                                 st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
                                 st->csr_indices, (int)st->n_items, st->seed, (uint64_t)st->step, w.u32, w.it32,

@@ -189,16 +189,27 @@ __device__ __forceinline__ void hsk_user_grad(hsk_row<V, NCH>& acc, float& gbias
                                               int D, int lane) {
   hsk_row_load<V, NCH, FULL>(acc, dUb + (long long)b0 * D, lane, D);
   if (c > 1) {
-    for (int c0 = (b0 / 64) * 64; c0 < B; c0 += 64) {
-      const int bb = c0 + lane;
-      const bool match = (bb < B) && (bb > b0) && (u32[bb] == row);
-      unsigned long long mask = __ballot(match);
-      while (mask) {
-        const int j = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        hsk_row<V, NCH> t;
-        hsk_row_load<V, NCH, FULL>(t, dUb + (long long)(c0 + j) * D, lane, D);
-        hsk_row_add(acc, t);
+    // duplicates of this user further down the batch, in ascending b; the id loads of 8 chunks (512 entries) are
+    // issued together so the scan costs a handful of memory latencies, not one per chunk
+    int found = 1;
+    for (int g0 = (b0 / 64) * 64; g0 < B && found < c; g0 += 512) {
+      int ids[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int bb = g0 + q * 64 + lane;
+        ids[q] = (bb < B && bb > b0) ? u32[bb] : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        unsigned long long mask = __ballot(ids[q] == row);
+        while (mask) {
+          const int j = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          hsk_row<V, NCH> t;
+          hsk_row_load<V, NCH, FULL>(t, dUb + (long long)(g0 + q * 64 + j) * D, lane, D);
+          hsk_row_add(acc, t);
+          ++found;
+        }
       }
     }
   }
@@ -280,23 +291,30 @@ __device__ __forceinline__ hsk_adamw_consts hsk_consts_at(const hsk_adamw_consts
   return c;
 }
 
-template <int V, int NCH, bool FULL>
-__device__ __forceinline__ void hsk_row_catch_up(hsk_row<V, NCH>& p, hsk_row<V, NCH>& m, hsk_row<V, NCH>& v, int from,
-                                                 int to, const hsk_adamw_consts& base,
-                                                 const float2* __restrict__ tab, int tab_len) {
-  // zero-gradient steps from+1 .. to (wave-uniform trip count)
-  for (int t = from + 1; t <= to; ++t) {
-    const hsk_adamw_consts c = hsk_consts_at(base, tab, tab_len, t);
+// Zero-gradient replay of one user row by a whole 256-thread workgroup (thread t owns VV consecutive elements per
+// pass): the replay is a serial chain of `to - from` dependent updates per element, so a row is spread over as
+// many lanes as it has elements instead of being held by one wave.
+template <int VV>
+__device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, float* __restrict__ mrow,
+                                                  float* __restrict__ vrow, int D, int from, int to,
+                                                  const hsk_adamw_consts& base, const float2* __restrict__ tab,
+                                                  int tab_len) {
+  for (int d0 = threadIdx.x * VV; d0 < D; d0 += 256 * VV) {
+    hsk_vec<VV> p = hsk_ldg<VV>(prow + d0), m = hsk_ldg<VV>(mrow + d0), v = hsk_ldg<VV>(vrow + d0);
+    for (int t = from + 1; t <= to; ++t) {
+      const hsk_adamw_consts c = hsk_consts_at(base, tab, tab_len, t);
 #pragma unroll
-    for (int cc = 0; cc < NCH; ++cc)
-#pragma unroll
-      for (int q = 0; q < V; ++q) hsk_adamw_update(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], 0.f, c);
+      for (int q = 0; q < VV; ++q) hsk_adamw_update(p.v[q], m.v[q], v.v[q], 0.f, c);
+    }
+    hsk_stg<VV>(prow + d0, p);
+    hsk_stg<VV>(mrow + d0, m);
+    hsk_stg<VV>(vrow + d0, v);
   }
 }
 
-// Lazy mode, before the forward: one wave per batch entry, the owner (lowest b) of each distinct user brings
+// Lazy mode, before the forward: one workgroup per batch entry; the owner (lowest b) of each distinct user brings
 // that user's row up to step-1, so the gather/score kernels read current parameters.
-template <int V, int NCH, bool FULL>
+template <int VV>
 __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, float* __restrict__ mU,
                                                        float* __restrict__ vU, float* __restrict__ Ub,
                                                        float* __restrict__ mUb, float* __restrict__ vUb,
@@ -304,27 +322,15 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
                                                        int* __restrict__ last_step, int B, int D, int step,
                                                        hsk_adamw_consts c, const float2* __restrict__ tab,
                                                        int tab_len) {
-  const int lane = hsk_lane();
-  const int wave = hsk_uniform_i(threadIdx.x >> 6);
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
-  const int row = hsk_uniform_i(u32[b]);
-  if (hsk_uniform_i(owner[row]) != b) return;
-  const int done = hsk_uniform_i(last_step[row]);
+  const int b = blockIdx.x;
+  const int row = u32[b];
+  if (owner[row] != b) return;
+  const int done = last_step[row];
   if (done >= step - 1) return;
-  using Row = hsk_row<V, NCH>;
-  float* prow = Uw + (long long)row * D;
-  float* mrow = mU + (long long)row * D;
-  float* vrow = vU + (long long)row * D;
-  Row p, m, v;
-  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
-  hsk_row_catch_up<V, NCH, FULL>(p, m, v, done, step - 1, c, tab, tab_len);
-  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
-  if (lane == 0) {
+  hsk_row_replay_wg<VV>(Uw + (long long)row * D, mU + (long long)row * D, vU + (long long)row * D, D, done, step - 1,
+                        c, tab, tab_len);
+  __syncthreads();  // every thread has read last_step[row]
+  if (threadIdx.x == 0) {
     if (Ub) {
       float pb = Ub[row], mb = mUb[row], vb = vUb[row];
       for (int t = done + 1; t <= step - 1; ++t) hsk_adamw_update(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
@@ -385,32 +391,20 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
   }
 }
 
-// bring every row with last_step < step up to `step` (one wave per table row)
-template <int V, int NCH, bool FULL>
+// bring every row with last_step < step up to `step` (one workgroup per table row)
+template <int VV>
 __global__ __launch_bounds__(256) void k_user_flush(float* __restrict__ Uw, float* __restrict__ mU,
                                                     float* __restrict__ vU, float* __restrict__ Ub,
                                                     float* __restrict__ mUb, float* __restrict__ vUb,
                                                     int* __restrict__ last_step, int n_users, int D, int step,
                                                     hsk_adamw_consts c, const float2* __restrict__ tab, int tab_len) {
-  const int lane = hsk_lane();
-  const int wave = hsk_uniform_i(threadIdx.x >> 6);
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= n_users) return;
-  const int done = hsk_uniform_i(last_step[row]);
+  const int row = blockIdx.x;
+  const int done = last_step[row];
   if (done >= step) return;
-  using Row = hsk_row<V, NCH>;
-  float* prow = Uw + (long long)row * D;
-  float* mrow = mU + (long long)row * D;
-  float* vrow = vU + (long long)row * D;
-  Row p, m, v;
-  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
-  hsk_row_catch_up<V, NCH, FULL>(p, m, v, done, step, c, tab, tab_len);
-  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
-  if (lane == 0) {
+  hsk_row_replay_wg<VV>(Uw + (long long)row * D, mU + (long long)row * D, vU + (long long)row * D, D, done, step, c,
+                        tab, tab_len);
+  __syncthreads();
+  if (threadIdx.x == 0) {
     if (Ub) {
       float pb = Ub[row], mb = mUb[row], vb = vUb[row];
       for (int t = done + 1; t <= step; ++t) hsk_adamw_update(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));

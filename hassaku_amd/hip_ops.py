@@ -167,7 +167,7 @@ class BprMfFusedState:
 
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, seed=0,
-                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True):
+                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=False):
         _lib.require_gpu()
         self.lib = _lib.load()
         n_users, dim = user_emb.shape
@@ -217,7 +217,14 @@ class BprMfFusedState:
         st.lazy_users = 1 if lazy_users else 0
         st.timing_mask = 0
         st.timing = None
+        st.timing_every = 1
+        st.timing_now = 0
         self._timing = None
+        # optional side stream for the item sort / loss reduction.  Measured on MI355X (profiles/README.md): the
+        # forward kernel fills every wave slot, the side kernels only run in its shadow and the cross-stream
+        # event waits cost ~6 us each -> no gain, so it is off by default.
+        self._aux = self.lib.hsk_aux_create() if overlap else None
+        st.aux = self._aux
         st.loss_out, st.status = _p(self.loss_out), _p(self.status)
         self.st = st
         _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(st), _stream()), 'hsk_bprmf_init_workspace')
@@ -254,8 +261,8 @@ class BprMfFusedState:
 
     STAGES = ('prep', 'scan', 'scatter', 'fwd', 'item', 'user', 'finish')
 
-    def enable_timing(self, stages=('fwd',)):
-        """Bracket the named stages of every following step with HIP events on the launch stream."""
+    def enable_timing(self, stages=('fwd',), every=1):
+        """Bracket the named stages of every `every`-th following step with HIP events on the launch stream."""
         if not getattr(self, '_timing', None):
             self._timing = self.lib.hsk_timing_create()
         mask = 0
@@ -263,6 +270,7 @@ class BprMfFusedState:
             mask |= 1 << self.STAGES.index(s)
         self.st.timing = self._timing
         self.st.timing_mask = mask
+        self.st.timing_every = int(every)
 
     def disable_timing(self):
         self.st.timing_mask = 0
@@ -285,6 +293,14 @@ class BprMfFusedState:
             except Exception:
                 pass
             self._timing = None
+        a = getattr(self, '_aux', None)
+        if a:
+            try:
+                torch.cuda.synchronize()
+                self.lib.hsk_aux_destroy(a)
+            except Exception:
+                pass
+            self._aux = None
 
     def flush(self):
         _lib.check(self.lib.hsk_bprmf_flush(ctypes.byref(self.st), _stream()), 'hsk_bprmf_flush')

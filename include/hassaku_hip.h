@@ -147,6 +147,12 @@ typedef struct hsk_bprmf_state {
   int32_t timing_mask;
   /* opaque handle from hsk_timing_create, or NULL (no timing) */
   void* timing;
+  /* opaque handle from hsk_aux_create, or NULL: side stream on which the item sort and the loss reduction of a
+     step run concurrently with the forward kernel (forked from / joined back into `stream` with events) */
+  void* aux;
+  /* event-time only every timing_every-th step (<= 1: every step); timing_now is library scratch */
+  int32_t timing_every;
+  int32_t timing_now;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;
@@ -187,6 +193,11 @@ enum {
 void* hsk_timing_create(void);
 void hsk_timing_destroy(void* timing);
 int hsk_timing_collect(void* timing, double* ms_sum, int64_t* count);
+
+/* Side stream + events for intra-step overlap (host-side objects; create once per state, destroy after the
+ * last step has completed).  Returns NULL on failure. */
+void* hsk_aux_create(void);
+void hsk_aux_destroy(void* aux);
 
 /* Bring lazily-updated user rows up to st->step (no-op when lazy_users == 0). */
 int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
