@@ -35,6 +35,7 @@ WORKLOADS = {
     'ml10m': ('ml10m', 512, 100, 4096),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_DIR = 'r1b_lazy_sorted'  # committed rocprofv3 summaries of `bench.py` (profiles/README.md)
 LR, WD = 3e-4, 4e-5    # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
@@ -42,6 +43,19 @@ def fwd_read_bytes(B, N, D):
     """Algorithmic HBM read bytes of one k_fwd_ugrad launch (negatives read from memory):
     user rows + (1+N) item rows per positive, item bias, item ids, user ids."""
     return 4 * D * B * (2 + N) + 4 * B * (1 + N) + 4 * B * (1 + N) + 4 * B
+
+
+def pmc_traffic_bytes(kernel_prefix, profile_dir):
+    """HBM-side traffic of one launch from the committed rocprofv3 PMC passes of this same command
+    (`tools_profile.sh`; FETCH_SIZE and WRITE_SIZE are collected in separate runs and reported in KB).  On gfx950
+    FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM): x2."""
+    path = os.path.join(REPO, 'profiles', profile_dir, 'pmc_summary.json')
+    if not os.path.isfile(path):
+        return None
+    for name, row in json.load(open(path)).items():
+        if name.startswith(kernel_prefix) and 'FETCH_SIZE_KB_mean' in row and 'WRITE_SIZE_KB_mean' in row:
+            return (2.0 * row['FETCH_SIZE_KB_mean'] + row['WRITE_SIZE_KB_mean']) * 1024.0
+    return None
 
 
 def build_state(data, D, B, N, device, seed=64, **kw):
@@ -162,7 +176,9 @@ def main():
                    'loss_last_step': loss},
         'roofline': {'bound': 'hbm', 'kernel': 'k_fwd_ugrad (gather + scores + BPR + user-row grad)',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': None, 'avg_us': fwd_us, 'launches': fwd_n,
+                     'traffic': pmc_traffic_bytes('k_fwd_ugrad', PROFILE_DIR) if args.workload == 'ml10m' else None,
+                     'traffic_source': f'profiles/{PROFILE_DIR}/pmc_summary.json (rocprofv3 --pmc, same command)',
+                     'avg_us': fwd_us, 'launches': fwd_n,
                      'algorithmic_bytes_per_launch': fwd_read_bytes(B, N, D)},
     }
     if args.time_all_stages:
