@@ -75,6 +75,31 @@ def build_state(data, D, B, N, device, seed=64, **kw):
     return st, csr
 
 
+def build_sharded_state(data, D, B, N, device, seed=64):
+    """world > 1: row-sharded user tables + replicated item table (hassaku_amd/dist.py); B positives per rank."""
+    from hassaku_amd.data.csr import UserItemCsr
+    from hassaku_amd.dist import Comm, ShardedBprMf
+    comm = Comm()
+    U, I = data.n_users, data.n_items
+    csr = UserItemCsr.from_pairs(data.train[:, 0], data.train[:, 1], U, I)
+    torch.manual_seed(seed)                                   # same initial tables on every rank
+    user_emb = torch.empty((U, D), device=device).normal_(std=0.1 / D)
+    item_emb = torch.empty((I, D), device=device).normal_(std=0.1 / D)
+    item_bias = torch.empty((I,), device=device).normal_(std=0.1)
+    indptr, indices = csr.to_device(device)
+    coo_u = torch.from_numpy(data.train[:, 0].astype(np.int32)).to(device)
+    coo_i = torch.from_numpy(data.train[:, 1].astype(np.int32)).to(device)
+    st = ShardedBprMf(comm, user_emb, item_emb, item_bias, lr=LR, wd=WD, batch=B, n_neg=N, csr_indptr=indptr,
+                      csr_indices=indices, coo_user=coo_u, coo_item=coo_i, seed=seed)
+    del user_emb
+    return st, csr, comm
+
+
+def hip_stage_names(st):
+    from hassaku_amd.hip_ops import BprMfFusedState
+    return BprMfFusedState.STAGES if isinstance(st, BprMfFusedState) else ('fwd', 'item')
+
+
 def usable_cores():
     """CPU share of this process: affinity mask, capped by the cgroup quota (a GPU box hands out 16 of its cores)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -106,6 +131,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='ml10m', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU-baseline work (0 = skip)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' "
+                    "stages collectives through the host and lets several ranks share one GPU: functional rehearsal only)")
     ap.add_argument('--overlap', action='store_true', help='item sort + loss reduction on a side stream')
     ap.add_argument('--dense-users', action='store_true', help='dense AdamW sweep over the user table every step')
     ap.add_argument('--time-all-stages', action='store_true', help='event-time every stage (perturbs the step time)')
@@ -118,44 +145,66 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from hassaku_amd.data import synthetic
     shape, D, N, B = WORKLOADS[args.workload]
-    data = synthetic.generate_named(shape, seed=0)
-    st, csr = build_state(data, D, B, N, device, overlap=args.overlap, lazy_users=not args.dense_users)
+    data = synthetic.generate_named(shape, seed=0)          # same seed on every rank: identical data everywhere
     nnz = data.train.shape[0]
-    if world > 1:
-        raise SystemExit('multi-GPU bench: not wired in this build')
+    comm = None
+    if world == 1:
+        st, csr = build_state(data, D, B, N, device, overlap=args.overlap, lazy_users=not args.dense_users)
+    else:
+        st, csr, comm = build_sharded_state(data, D, B, N, device)
 
     gen = torch.Generator(device=device)
     gen.manual_seed(64)
-    order = torch.randperm(nnz, device=device, generator=gen)
-    n_batches = nnz // B
+    order = torch.randperm(nnz, device=device, generator=gen)   # identical on every rank (same seed)
+    n_batches = nnz // (B * world)
 
     def run(n, first):
         for s in range(n):
-            st.step_sampled(order, ((first + s) % n_batches) * B, B, N)
+            start = ((first + s) % n_batches) * B * world        # global batch = world * B positives (weak scaling)
+            if world == 1:
+                st.step_sampled(order, start, B, N)
+            else:
+                st.step_sampled(order, start)
+
+    def fence():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
 
     run(args.warmup, 0)
-    torch.cuda.synchronize()
+    fence()
     st.check_status('warm-up')
     # every stage on every step when asked; otherwise only the roofline kernel, on every 8th step, so that the
     # event records (each costs a few us of launch gap) do not distort the step time being measured
-    st.enable_timing(st.STAGES if args.time_all_stages else ('fwd',), every=1 if args.time_all_stages else 8)
-    torch.cuda.synchronize()
+    stages = hip_stage_names(st) if args.time_all_stages else ('fwd',)
+    st.enable_timing(stages, every=1 if args.time_all_stages else 8)
+    fence()
     t0 = time.perf_counter()
     run(args.steps, args.warmup)
     st.flush()   # lazily updated user rows are brought up to date INSIDE the timed region: no work is skipped
-    torch.cuda.synchronize()
+    fence()
     t1 = time.perf_counter()
     st.disable_timing()
     elapsed = t1 - t0
+    if comm is not None:                                          # the slowest rank defines the step time
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     timing = st.collect_timing()
     st.check_status('timed region')
     loss = st.last_loss()
@@ -172,7 +221,10 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{args.workload}-shaped synthetic, mf + bpr + adamw, embedding_dim={D}, '
                                f'neg_train={N}, batch={B}, U={data.n_users}, I={data.n_items}, nnz_train={nnz}',
-                   'global_batch': B * world, 'parallelism': f'dp{world}', 'lr': LR, 'wd': WD,
+                   'global_batch': B * world,
+                   'parallelism': 'single GPU' if world == 1 else
+                   f'{world} ranks: user tables row-sharded (all_to_all), item table replicated (all_reduce)',
+                   'lr': LR, 'wd': WD,
                    'loss_last_step': loss},
         'roofline': {'bound': 'hbm', 'kernel': 'k_fwd_ugrad (gather + scores + BPR + user-row grad)',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -39,6 +39,21 @@ class HskBprmfState(ctypes.Structure):
     ]
 
 
+class HskBprmfMp(ctypes.Structure):
+    """Mirror of `struct hsk_bprmf_mp` (include/hassaku_hip.h)."""
+    _fields_ = [
+        ('base', HskBprmfState),
+        ('world', c_int32), ('rank', c_int32),
+        ('n_users_global', c_int64), ('capacity', c_int64),
+        ('req_send', c_void_p), ('req_recv', c_void_p),
+        ('rows_send', c_void_p), ('rows_recv', c_void_p),
+        ('grads_send', c_void_p), ('grads_recv', c_void_p),
+        ('g_item_emb', c_void_p), ('g_item_bias', c_void_p),
+        ('slot_of_b', c_void_p),
+        ('cur_batch', c_int64), ('cur_cols', c_int64),
+    ]
+
+
 # name -> (restype, argtypes); every symbol of include/hassaku_hip.h
 SIGNATURES = {
     'hsk_version': (c_int, []),
@@ -62,6 +77,11 @@ SIGNATURES = {
     'hsk_timing_collect': (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     'hsk_aux_create': (c_void_p, []),
     'hsk_aux_destroy': (None, [c_void_p]),
+    'hsk_mp_prep': (c_int, [POINTER(HskBprmfMp), c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    'hsk_mp_serve': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_compute': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_apply': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_flush': (c_int, [POINTER(HskBprmfMp), c_void_p]),
     'hsk_bprmf_flush': (c_int, [POINTER(HskBprmfState), c_void_p]),
     'hsk_bprmf_last_batch': (c_int, [POINTER(HskBprmfState), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'hsk_mf_eval_topk': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,

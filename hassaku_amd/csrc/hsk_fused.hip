@@ -454,3 +454,7 @@ extern "C" int hsk_sample_negatives_uniform(const int64_t* csr_indptr, const int
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
+
+// multi-GPU phases (row-sharded user tables)
+#include <algorithm>
+#include "hsk_mp.inc"

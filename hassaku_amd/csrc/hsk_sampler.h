@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
                                                      uint64_t seed, uint64_t stream_id, int* __restrict__ u32,
                                                      int* __restrict__ it32,
                                                      int* __restrict__ owner, int* __restrict__ cnt,
-                                                     int32_t* status) {
+                                                     int32_t* status, int b_offset = 0) {
+  // b_offset: position of this rank's slice inside the global batch.  The RNG counter uses the GLOBAL batch
+  // position, so N ranks with slices of B draw exactly what one device draws for a batch of N*B.
+  // owner == NULL: no owner map (row-sharded user tables build it on the owning rank instead).
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
@@ -92,15 +95,17 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
   const int K = n_neg + 1;
   int* row = it32 + (long long)b * K;
   for (int n = lane; n < n_neg; n += 64) {
-    const int neg = hsk_draw_negative(csr_indices, lo, hi, (uint32_t)n_items, (uint32_t)b, (uint32_t)n, seed,
-                                      stream_id, status);
+    const int neg = hsk_draw_negative(csr_indices, lo, hi, (uint32_t)n_items, (uint32_t)(b + b_offset), (uint32_t)n,
+                                      seed, stream_id, status);
     row[1 + n] = neg;
   }
   if (lane == 0) {
     row[0] = ipos;
     u32[b] = u;
-    atomicMin(&owner[u], b);
-    atomicAdd(&cnt[u], 1);
+    if (owner) {
+      atomicMin(&owner[u], b);
+      atomicAdd(&cnt[u], 1);
+    }
   }
 }
 

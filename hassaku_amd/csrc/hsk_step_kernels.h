@@ -13,7 +13,8 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
                                                    const float* __restrict__ Ib, const int* __restrict__ u32,
                                                    const int* __restrict__ it32, int B, int K, int D,
                                                    float inv_bn, float* __restrict__ g_s,
-                                                   float* __restrict__ dUb, double* __restrict__ loss_b) {
+                                                   float* __restrict__ dUb, double* __restrict__ loss_b,
+                                                   const int* __restrict__ dU_index = nullptr) {
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
   const float g0 = -gsum;
   hsk_row_axpy(acc, g0, r0);
   if (lane == 0) g_s[(long long)b * K] = g0;
-  hsk_row_store<V, NCH, FULL>(acc, dUb + (long long)b * D, lane, D);
+  // row-sharded user tables: the gradient row goes straight into its slot of the all-to-all send buffer
+  hsk_row_store<V, NCH, FULL>(acc, dUb + (long long)(dU_index ? hsk_uniform_i(dU_index[b]) : b) * D, lane, D);
   const double l = hsk_wave_sum_f64(lsum);
   if (lane == 0) loss_b[b] = l;
 }
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
                                                        int tab_len) {
   const int b = blockIdx.x;
   const int row = u32[b];
+  if (row < 0) return;  // empty exchange slot (row-sharded mode)
   if (owner[row] != b) return;
   const int done = last_step[row];
   if (done >= step - 1) return;
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
   const int b = blockIdx.x * 4 + wave;
   if (b >= B) return;
   const int row = hsk_uniform_i(u32[b]);
+  if (row < 0) return;  // empty exchange slot (row-sharded mode)
   if (hsk_uniform_i(owner[row]) != b) return;
   using Row = hsk_row<V, NCH>;
   const int n = hsk_uniform_i(cnt[row]);

@@ -48,6 +48,17 @@ class UserItemCsr:
         return UserItemCsr.from_pairs(np.concatenate([ru, ro]), np.concatenate([self.indices, other.indices]),
                                       self.n_rows, self.n_cols)
 
+    def subset_rows(self, first: int, stride: int) -> 'UserItemCsr':
+        """Rows first, first+stride, ... as a new CSR (row j of the result = row first + j*stride): the local
+        view of a table that is row-sharded by `row % stride == first`."""
+        rows = np.arange(first, self.n_rows, stride)
+        lens = self.row_lengths()[rows]
+        indptr = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum(lens, out=indptr[1:])
+        starts = self.indptr[rows]
+        idx = np.repeat(starts - indptr[:-1], lens) + np.arange(indptr[-1])
+        return UserItemCsr(indptr, self.indices[idx], len(rows), self.n_cols)
+
     def to_scipy(self, dtype=bool):
         from scipy import sparse as sp
         return sp.csr_matrix((np.ones(self.nnz, dtype=dtype), self.indices, self.indptr),

@@ -48,9 +48,19 @@ class Trainer:
             raise ValueError(f"Optimizer {conf['optimizer']} not yet implemented")
 
         self.fused: Optional[hip_ops.BprMfFusedState] = None
+        self.sharded = None   # hassaku_amd.dist.ShardedBprMf when launched with one process per GPU
+        self.comm = None
         want_fused = conf.get('fused_step', True)
-        if (want_fused and isinstance(model, SGDMatrixFactorization)
-                and isinstance(rec_loss, RecBayesianPersonalizedRankingLoss) and conf['optimizer'] == 'adamw'):
+        fusable = (isinstance(model, SGDMatrixFactorization) and isinstance(rec_loss, RecBayesianPersonalizedRankingLoss)
+                   and conf['optimizer'] == 'adamw')
+        import torch.distributed as tdist
+        multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+        if multi:
+            if not (fusable and isinstance(train_loader, TrainDataLoader)):
+                raise RuntimeError('multi-GPU training supports mf + bpr + adamw with the device TrainDataLoader')
+            self.sharded = self._build_sharded(conf)
+            self.optimizer = None
+        elif want_fused and fusable:
             self.fused = self._build_fused(conf)
             self.optimizer = None
         else:
@@ -81,6 +91,49 @@ class Trainer:
             seed = conf['running_settings'].get('seed', 64)
         return hip_ops.BprMfFusedState(user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd, max_batch=max_batch,
                                        max_cols=n_neg + 1, seed=seed, **kw)
+
+    def _build_sharded(self, conf):
+        from hassaku_amd.dist import Comm, ShardedBprMf
+        self.comm = Comm()
+        user_emb, item_emb, ib, ub, gb = self.model.tables()
+        loader = self.train_loader
+        arrays = loader.dataset.device_arrays(torch.device(self.device))
+        return ShardedBprMf(self.comm, user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd,
+                            batch=loader.batch_size, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed, **arrays)
+
+    def _sync_model_from_shards(self):
+        """Assemble the row-sharded user table into the model's parameters (every rank), e.g. before saving."""
+        full_u, full_ub = self.sharded.gather_user_table()
+        self.pointer_to_model.user_embeddings.weight.data.copy_(full_u)
+        if full_ub is not None:
+            self.pointer_to_model.user_bias.weight.data.copy_(full_ub.view(-1, 1))
+
+    def _save(self):
+        if self.sharded is not None:
+            self._sync_model_from_shards()
+            if self.comm.rank == 0:
+                self.pointer_to_model.save_model_to_path(self.model_path)
+            self.comm.barrier()
+        else:
+            self.pointer_to_model.save_model_to_path(self.model_path)
+
+    def _train_epoch_sharded(self):
+        """Global batch = world x train_batch_size positives per step; rank r takes the r-th slice.  The last
+        (ragged) global batch is split evenly; at most world-1 interactions per epoch are left out."""
+        loader, sh, W = self.train_loader, self.sharded, self.comm.world
+        order = loader._epoch_order()
+        loader.epoch += 1
+        n, bs = len(loader.dataset), loader.batch_size
+        steps, pos = 0, 0
+        while n - pos >= W:
+            nb = min(bs, (n - pos) // W)
+            sh.step_sampled(order, pos, nb)
+            pos += nb * W
+            steps += 1
+        sh.flush()
+        rec = sh.pop_loss_sum() / max(steps, 1)
+        sh.check_status()
+        return {'epoch_train_loss': rec, 'epoch_train_rec_loss': rec, 'epoch_train_reg_loss': 0.0}
 
     def _log(self, log_dict):
         if self.use_wandb and not self._in_tune:
@@ -143,14 +196,19 @@ class Trainer:
         self._post_val(-1, log_dict)
         print('Init - Avg Val Value {:.3f} \n'.format(self.best_value))
         self._log(log_dict)
-        self.pointer_to_model.save_model_to_path(self.model_path)
+        self._save()
 
         for epoch in trange(self.n_epochs, disable=not self.batch_verbose):
             self.model.train()
             if patience == 0:
                 print('Ran out of patience, Stopping ')
                 break
-            losses = self._train_epoch_fused() if self.fused is not None else self._train_epoch_autograd()
+            if self.sharded is not None:
+                losses = self._train_epoch_sharded()
+            elif self.fused is not None:
+                losses = self._train_epoch_fused()
+            else:
+                losses = self._train_epoch_autograd()
             print('Epoch {} - Epoch Avg Train Loss {:.4f} ({:.4f} Rec Loss + {:.4f} Reg Loss )\n'.format(
                 epoch, losses['epoch_train_loss'], losses['epoch_train_rec_loss'], losses['epoch_train_reg_loss']))
 
@@ -162,7 +220,7 @@ class Trainer:
                 self.best_epoch = metrics['best_epoch'] = epoch
                 self.best_metrics = metrics
                 print('Epoch {} - New best model found (val value {:.4f}) \n'.format(epoch, current))
-                self.pointer_to_model.save_model_to_path(self.model_path)
+                self._save()
                 patience = self.max_patience
             else:
                 metrics['max_optimizing_metric'] = self.best_value
@@ -178,6 +236,11 @@ class Trainer:
         if self.fused is not None:
             self.fused.flush()
         dataset = self.val_loader.dataset
+        if self.sharded is not None:
+            from hassaku_amd.dist import evaluate_sharded
+            evaluator = FullEvaluator(aggr_by_group=True, n_groups=dataset.n_user_groups,
+                                      user_to_user_group=dataset.user_to_user_group)
+            return evaluate_sharded(self.comm, self.sharded, dataset, evaluator)
         evaluator = FullEvaluator(aggr_by_group=True, n_groups=dataset.n_user_groups,
                                   user_to_user_group=dataset.user_to_user_group)
         return evaluate_recommender_algorithm(self.pointer_to_model, self.val_loader, evaluator, self.device,

@@ -207,6 +207,57 @@ int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_col
                          int64_t* u_out, int64_t* i_out, hsk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-GPU fused step: one process per GPU; replaces nn.DataParallel (train/trainer.py:38-41).
+ *
+ * User tables are ROW-SHARDED: rank r owns the users u with u % world == r, stored at local row u / world
+ * (base.user_emb and its moments hold only the local rows, base.n_users = number of local rows).  The item
+ * table is replicated.  A step processes a global batch of world*batch positives; rank r takes positions
+ * [r*batch, (r+1)*batch).  The library runs the compute phases; the caller runs the collectives between
+ * them (RCCL through torch.distributed, or anything else that moves the buffers below):
+ *
+ *   hsk_mp_prep      sample the local slice (RNG keyed by the GLOBAL batch position), sort its entries by item,
+ *                    route each positive's user to its owner: req_send[dst*C + s] = local row at dst, or -1
+ *     all_to_all(req_send -> req_recv)                                    4*world*C bytes per rank
+ *   hsk_mp_serve     owner: replay missed zero-gradient steps of the requested rows, pack them into rows_send
+ *     all_to_all(rows_send -> rows_recv)                                  4*D*world*C bytes per rank
+ *   hsk_mp_compute   forward + BPR + user-row grads (-> grads_send) + dense partial item gradient
+ *     all_reduce(g_item_emb, g_item_bias; sum)                            4*(D+1)*I bytes
+ *     all_to_all(grads_send -> grads_recv)                                4*D*world*C bytes per rank
+ *   hsk_mp_apply     AdamW on the (replicated) item table with the reduced gradient; owner: AdamW on the
+ *                    requested user rows (duplicates summed in slot order); loss_out[0] = this rank's share of
+ *                    the global mean loss (sum over ranks = loss), loss_out[1] accumulates it
+ *
+ * Result = the single-GPU step on the global batch (same samples; fp32 summation order of the item gradient
+ * differs).  C = capacity (slots per rank pair); HSK_STATUS_ROUTE_OVERFLOW is raised if a pair needs more.
+ * ------------------------------------------------------------------------------------------ */
+enum { HSK_STATUS_ROUTE_OVERFLOW = 4 };
+
+typedef struct hsk_bprmf_mp {
+  hsk_bprmf_state base;       /* local user shard + replicated item table; base.max_batch >= max(batch, world*C) */
+  int32_t world, rank;
+  int64_t n_users_global;
+  int64_t capacity;           /* C */
+  int32_t* req_send;          /* [world*C] */
+  int32_t* req_recv;          /* [world*C] */
+  float* rows_send;           /* [world*C, D] */
+  float* rows_recv;           /* [world*C, D] */
+  float* grads_send;          /* [world*C, D] */
+  float* grads_recv;          /* [world*C, D] */
+  float* g_item_emb;          /* [I, D] */
+  float* g_item_bias;         /* [I] (NULL without item bias) */
+  int32_t* slot_of_b;         /* [batch] */
+  int64_t cur_batch, cur_cols; /* library scratch: shape of the step in flight */
+} hsk_bprmf_mp;
+
+int hsk_mp_prep(hsk_bprmf_mp* mp, const int64_t* order, int64_t start_global, int64_t batch, int64_t n_neg,
+                hsk_stream_t stream);
+int hsk_mp_serve(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int hsk_mp_compute(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int hsk_mp_apply(hsk_bprmf_mp* mp, hsk_stream_t stream);
+/* bring every local user row up to date (before evaluation / gathering the table) */
+int hsk_mp_flush(hsk_bprmf_mp* mp, hsk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Full-catalogue evaluation (eval/eval.py:237-253, eval/eval.py:54-99, eval/metrics.py:4-105)
  * ------------------------------------------------------------------------------------------ */
 
