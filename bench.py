@@ -169,7 +169,9 @@ def main():
 
     gen = torch.Generator(device=device)
     gen.manual_seed(64)
-    order = torch.randperm(nnz, device=device, generator=gen)   # identical on every rank (same seed)
+    order = torch.randperm(nnz, device=device, generator=gen)
+    if comm is not None:
+        comm.broadcast(order, src=0)                              # one epoch order for the whole job
     n_batches = nnz // (B * world)
 
     def run(n, first):

@@ -72,6 +72,14 @@ class Comm:
         dist.all_gather(parts, h, group=self.group)
         return [p.to(inp.device) for p in parts]
 
+    def broadcast(self, t: torch.Tensor, src: int = 0):
+        if self.native or not t.is_cuda:
+            dist.broadcast(t, src=src, group=self.group)
+        else:
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            t.copy_(h)
+
     def barrier(self):
         dist.barrier(group=self.group)
 
@@ -111,6 +119,10 @@ class ShardedBprMf:
         self.device, self.n_users_global, self.n_items, self.dim = dev, U, I, D
         self.batch, self.n_neg = int(batch), int(n_neg)
         self.capacity = C = int(capacity or pair_capacity(self.batch, W))
+        # the replicated tables must start bit-identical on every rank: rank 0's copy wins
+        for t in (item_emb, item_bias, global_bias):
+            if t is not None:
+                comm.broadcast(t, src=0)
         # local shards (own storage: the full table is not referenced afterwards)
         self.user_emb = user_emb[r::W].contiguous()
         self.user_bias = None if user_bias is None else user_bias.reshape(-1)[r::W].contiguous()

@@ -122,6 +122,8 @@ class Trainer:
         (ragged) global batch is split evenly; at most world-1 interactions per epoch are left out."""
         loader, sh, W = self.train_loader, self.sharded, self.comm.world
         order = loader._epoch_order()
+        if order is not None:
+            self.comm.broadcast(order, src=0)   # one epoch order for the whole job
         loader.epoch += 1
         n, bs = len(loader.dataset), loader.batch_size
         steps, pos = 0, 0
