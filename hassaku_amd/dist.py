@@ -274,6 +274,65 @@ class ShardedBprMf:
         return gather(self.user_emb), (None if self.user_bias is None else gather(self.user_bias))
 
 
+def evaluate_item_sharded(comm: Comm, user_emb, item_emb, item_bias, user_bias, global_bias, dataset, evaluator,
+                          chunk: int = 1024):
+    """ITEM-sharded full evaluation (BASELINE config 4): rank r scores every user against the item range it owns
+    (`hsk_mf_eval_topk` with item_begin/item_count), keeps its local top-k, the (value, id) candidate lists are
+    all-gathered (k*8 bytes per user and rank) and merged to the global top-k (`hsk_topk_merge`); metrics are then
+    computed for this rank's slice of the users and all-reduced.  Tables are passed whole (replicated) here; a rank
+    only reads its item rows, so the same code serves a table that is physically sharded by item range.
+    `user_emb` is the FULL user table (e.g. `ShardedBprMf.gather_user_table()`)."""
+    W, r = comm.world, comm.rank
+    dev = user_emb.device
+    arr = dataset.device_arrays(dev)
+    n_users, n_items = user_emb.shape[0], item_emb.shape[0]
+    lo_i = (n_items * r) // W
+    hi_i = (n_items * (r + 1)) // W
+    ks = sorted(evaluator.K_VALUES, reverse=True)
+    k = ks[0]
+    kk = min(k, hi_i - lo_i)
+    n_groups = evaluator.get_n_groups()
+    groups = evaluator.get_user_to_user_group().to(dev) if n_groups > 0 else None
+    sums = torch.zeros((n_groups + 1, len(ks), 3), dtype=torch.float64, device=dev)
+    counts = torch.zeros(n_groups + 1, dtype=torch.float64, device=dev)
+    status = hip_ops.new_status(dev)
+    with torch.no_grad():
+        for lo in range(0, n_users, chunk):
+            u = torch.arange(lo, min(lo + chunk, n_users), device=dev)
+            v, i, _ = hip_ops.mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u, kk,
+                                           arr['excl_indptr'], arr['excl_indices'], item_begin=lo_i,
+                                           item_count=hi_i - lo_i, status=status)
+            pv = torch.full((len(u), k), float('-inf'), device=dev)
+            pi = torch.full((len(u), k), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+            pv[:, :kk], pi[:, :kk] = v, i
+            cand_v = torch.stack(comm.all_gather(pv)).contiguous()      # [W, R, k]
+            cand_i = torch.stack(comm.all_gather(pi)).contiguous()
+            _, ids = hip_ops.topk_merge(cand_v, cand_i)
+            mine = slice(r, len(u), W)                                   # metrics: this rank's share of the chunk
+            um = u[mine].contiguous()
+            met = hip_ops.rank_metrics(ids[mine].contiguous(), um, arr['label_indptr'], arr['label_indices'], ks).double()
+            sums[0] += met.sum(0)
+            counts[0] += len(um)
+            for g in range(n_groups):
+                sel = groups[um] == g
+                sums[1 + g] += met[sel].sum(0)
+                counts[1 + g] += sel.sum()
+    hip_ops.raise_on_status(status, 'item-sharded eval')
+    comm.all_reduce(sums)
+    comm.all_reduce(counts)
+    return _metric_dict(sums.cpu(), counts.cpu(), ks, n_groups)
+
+
+def _metric_dict(sums, counts, ks, n_groups):
+    out = {}
+    for gi in range(n_groups + 1):
+        prefix = '' if gi == 0 else f'group_{gi - 1}_'
+        for t, k in enumerate(ks):
+            for j, name in enumerate(('precision', 'recall', 'ndcg')):
+                out[f'{prefix}{name}@{k}'] = float(sums[gi, t, j] / counts[gi])
+    return out
+
+
 def evaluate_sharded(comm: Comm, sharded: ShardedBprMf, dataset, evaluator, chunk: int = 1024):
     """Users-sharded full evaluation: this rank scores the users it owns; sums and counts are all-reduced.
     `dataset` is a FullEvalDataset; `evaluator` a FullEvaluator (only its K_VALUES / group map are used)."""

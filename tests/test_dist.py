@@ -185,8 +185,11 @@ def _gpu_worker(rank, world, port, out_dir):
     sh.check_status()
     full_u, full_ub = sh.gather_user_table()
 
-    class DS:   # the attributes evaluate_sharded reads from a FullEvalDataset
-        pass
+    class DS:   # the attributes the evaluators read from a FullEvalDataset
+        def device_arrays(self, device):
+            lp, li = self.label_csr.to_device(device)
+            ep, ei = self.exclude_csr.to_device(device)
+            return {'label_indptr': lp, 'label_indices': li, 'excl_indptr': ep, 'excl_indices': ei}
     ds = DS()
     ds.label_csr = UserItemCsr.from_pairs(val[:, 0], val[:, 1], U, I)
     ds.exclude_csr = UserItemCsr.from_pairs(pairs[:, 0], pairs[:, 1], U, I)
@@ -194,6 +197,11 @@ def _gpu_worker(rank, world, port, out_dir):
     groups = torch.from_numpy((np.arange(U) % 2).astype(np.float32))
     ev = FullEvaluator(aggr_by_group=True, n_groups=2, user_to_user_group=groups)
     metrics = evaluate_sharded(comm, sh, ds, ev, chunk=64)
+    from hassaku_amd.dist import evaluate_item_sharded
+    m_items = evaluate_item_sharded(comm, full_u, sh.item_emb, sh.item_bias, full_ub, None, ds, ev, chunk=50)
+    assert sorted(m_items) == sorted(metrics)
+    for k in metrics:   # item-sharded scoring + candidate all-gather + merge == users-sharded scoring
+        assert abs(m_items[k] - metrics[k]) < 1e-9, (k, m_items[k], metrics[k])
     if rank == 0:
         np.savez(os.path.join(out_dir, 'mp.npz'), U=full_u.cpu().numpy(), Ub=full_ub.cpu().numpy(),
                  I=sh.item_emb.cpu().numpy(), Ib=sh.item_bias.cpu().numpy(), losses=np.array(losses),
