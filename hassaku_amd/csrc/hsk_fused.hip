@@ -114,6 +114,8 @@ static int hsk_check_state(const hsk_bprmf_state* st) {
               "lazy_users needs bias corrections that saturate within %d steps (betas too close to 1)",
               HSK_ADAM_TAB_LEN);
   HSK_REQUIRE(st->step >= 0 && st->step < 0x7ffffff0, HSK_ERR_UNSUPPORTED, "step counter out of range");
+  HSK_REQUIRE(st->loss_kind >= HSK_LOSS_BPR && st->loss_kind <= HSK_LOSS_SSM, HSK_ERR_INVALID, "unknown loss_kind %d",
+              st->loss_kind);
   return HSK_OK;
 }
 
@@ -267,13 +269,20 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
   return HSK_OK;
 }
 
+// 1 / (number of terms the loss averages over)
+static inline double hsk_loss_norm(int kind, double batch, double n_cols) {
+  if (kind == HSK_LOSS_BCE) return 1.0 / (batch * n_cols);
+  if (kind == HSK_LOSS_SSM) return 1.0 / batch;
+  return 1.0 / (batch * (n_cols - 1.0));
+}
+
 // stages after prep filled u32 / it32 / owner / cnt
 static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t K, hipStream_t stream) {
   const int64_t total = B * K;
   const int I = (int)st->n_items, U = (int)st->n_users, D = (int)st->dim;
   st->step += 1;
   const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
-  const double inv_bn_d = 1.0 / ((double)B * (double)(K - 1));
+  const double inv_bn_d = hsk_loss_norm(st->loss_kind, (double)B, (double)K);
   const float inv_bn = (float)inv_bn_d;
 
   hsk_sort_plan plan;
@@ -325,9 +334,18 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
                                       w.adam_tab, HSK_ADAM_TAB_LEN)));
       }
     }
-    HSK_STAGE(HSK_STAGE_FWD, (k_fwd_ugrad<V, NCH, FULL, R><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
-                                 st->user_emb, st->item_emb, st->item_bias, w.u32, w.it32, (int)B, (int)K, D, inv_bn,
-                                 w.g_s, w.dUb, w.loss_b)));
+#define HSK_LAUNCH_FWD(LK)                                                                                         \
+  HSK_STAGE(HSK_STAGE_FWD, (k_fwd_ugrad<V, NCH, FULL, R, LK><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(         \
+                               st->user_emb, st->item_emb, st->item_bias, w.u32, w.it32, (int)B, (int)K, D, inv_bn, \
+                               (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b)))
+    if (st->loss_kind == HSK_LOSS_BCE) {
+      HSK_LAUNCH_FWD(HSK_LOSS_BCE);
+    } else if (st->loss_kind == HSK_LOSS_SSM) {
+      HSK_LAUNCH_FWD(HSK_LOSS_SSM);
+    } else {
+      HSK_LAUNCH_FWD(HSK_LOSS_BPR);
+    }
+#undef HSK_LAUNCH_FWD
     if (aux) {
       // side stream: loss reduction + global bias as soon as the forward is done; main: join the sort
       (void)hipEventRecord(aux->ev_fwd, stream);

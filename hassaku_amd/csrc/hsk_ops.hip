@@ -291,3 +291,55 @@ extern "C" int hsk_adamw_dense(float* p, const float* g, float* m, float* v, int
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
+
+// bce / sampled-softmax loss + gradient wrt logits, one wave per row (see hsk_rec_loss_grad in the header)
+__global__ __launch_bounds__(256) void k_rec_loss_grad(int kind, const float* __restrict__ logits, int B, long long K,
+                                                       float inv_norm, float log_adjust, float* __restrict__ grad,
+                                                       double* __restrict__ ws) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float* row = logits + (long long)b * K;
+  float* grow = grad ? grad + (long long)b * K : nullptr;
+  double lsum = 0.0;
+  if (kind == HSK_LOSS_BCE) {
+    for (long long k = lane; k < K; k += 64) {
+      const float s = row[k];
+      const bool pos = (k == 0);
+      lsum += (double)hsk_softplus(pos ? -s : s);
+      if (grow) grow[k] = pos ? -inv_norm / (1.f + expf(s)) : inv_norm / (1.f + expf(-s));
+    }
+  } else {  // sampled softmax
+    float mx = -INFINITY;
+    for (long long k = lane; k < K; k += 64) mx = fmaxf(mx, row[k] + (k == 0 ? 0.f : log_adjust));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+    for (long long k = lane; k < K; k += 64) sum += expf(row[k] + (k == 0 ? 0.f : log_adjust) - mx);
+    sum = hsk_wave_sum(sum);
+    const float rinv = inv_norm / sum;
+    if (grow)
+      for (long long k = lane; k < K; k += 64)
+        grow[k] = expf(row[k] + (k == 0 ? 0.f : log_adjust) - mx) * rinv - (k == 0 ? inv_norm : 0.f);
+    if (lane == 0) lsum = (double)(-row[0] + mx + logf(sum));
+  }
+  const double l = hsk_wave_sum_f64(lsum);
+  if (lane == 0) ws[b] = l;
+}
+
+extern "C" int hsk_rec_loss_grad(int32_t kind, const float* logits, int64_t batch, int64_t n_cols, double log_adjust,
+                                 double* loss, float* grad_logits, double* ws, hsk_stream_t stream_) {
+  if (kind == HSK_LOSS_BPR) return hsk_bpr_loss_grad(logits, batch, n_cols, loss, grad_logits, ws, stream_);
+  HSK_REQUIRE(kind == HSK_LOSS_BCE || kind == HSK_LOSS_SSM, HSK_ERR_INVALID, "unknown loss kind %d", kind);
+  HSK_REQUIRE(logits && loss && ws, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(batch > 0 && n_cols >= 2 && batch < 0x7fffffff, HSK_ERR_INVALID, "need batch > 0 and n_cols >= 2");
+  hipStream_t stream = (hipStream_t)stream_;
+  const double inv = (kind == HSK_LOSS_BCE) ? 1.0 / ((double)batch * (double)n_cols) : 1.0 / (double)batch;
+  k_rec_loss_grad<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(kind, logits, (int)batch, (long long)n_cols,
+                                                                        (float)inv, (float)log_adjust, grad_logits, ws);
+  HSK_LAUNCH_CHECK();
+  k_loss_mean<<<1, 1024, 0, stream>>>(ws, (int)batch, inv, loss);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}

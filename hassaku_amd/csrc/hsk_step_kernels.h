@@ -8,11 +8,20 @@
 //     reads:  4*D*(2+N) + 4*(1+N) + 4*(2+N) bytes per positive  (the "gather+BPR step" of SURVEY 8d)
 //     writes: g_s [B,1+N], dUb [B,D], loss_b [B]
 // =============================================================================================
-template <int V, int NCH, bool FULL, int R>
+// LOSS selects the recommendation loss evaluated on the (1+N) scores of a positive (train/rec_losses.py):
+//   HSK_LOSS_BPR  mean_{b,n} softplus(-(s_0 - s_n))                                   (:56-88)
+//   HSK_LOSS_BCE  mean_{b,k} BCEWithLogits(s_k, [k==0])                               (:27-53)
+//   HSK_LOSS_SSM  mean_b  -s_0 + logsumexp(s_0, s_1 + c, ..., s_N + c), c = log(I/N)  (:91-139, uniform sampling)
+// All three need every row once: BPR and BCE weigh a row as soon as its score (and s_0) is known; the sampled
+// softmax keeps a running max / normaliser and rescales the accumulated user-row gradient when the max moves
+// (online softmax), then rewrites its stored scores into gradients once the normaliser is final.
+// (HSK_LOSS_BPR / _BCE / _SSM are declared in hassaku_hip.h)
+
+template <int V, int NCH, bool FULL, int R, int LOSS>
 __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw, const float* __restrict__ Iw,
                                                    const float* __restrict__ Ib, const int* __restrict__ u32,
                                                    const int* __restrict__ it32, int B, int K, int D,
-                                                   float inv_bn, float* __restrict__ g_s,
+                                                   float inv_norm, float ssm_c, float* __restrict__ g_s,
                                                    float* __restrict__ dUb, double* __restrict__ loss_b,
                                                    const int* __restrict__ dU_index = nullptr) {
   const int lane = hsk_lane();
@@ -31,8 +40,10 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
   hsk_row_zero(acc);
   const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
 
-  float gsum = 0.f;    // sum over negatives of sigma(-x)/(B*N)   (wave-uniform)
-  double lsum = 0.0;   // per-lane partial of sum softplus(-x)
+  float gsum = 0.f;    // BPR: sum over negatives of sigma(-x)/(B*N)   (wave-uniform)
+  double lsum = 0.0;   // per-lane partial of the loss terms
+  float smax = s0, ssum = 1.f;   // SSM: running max and sum of exp(z - smax), z_0 = s_0
+  if (LOSS == HSK_LOSS_SSM) acc = r0;  // exp(z_0 - smax) = 1
 
   for (int kc = 1; kc < K; kc += 64) {
     const int nr = min(64, K - kc);
@@ -51,12 +62,34 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
       for (int r = 0; r < R; ++r) {
         if (j + r < nr) {
           const float s = hsk_wave_sum(hsk_row_dot_partial(ur, buf[r])) + hsk_readlane_f(mybias, j + r);
-          const float x = s0 - s;
-          const float g = inv_bn / (1.f + expf(x));  // sigma(-x)/(B*N) = d loss / d s_neg
-          hsk_row_axpy(acc, g, buf[r]);
-          gsum += g;
-          gv = (lane == j + r) ? g : gv;
-          xv = (lane == j + r) ? x : xv;
+          if (LOSS == HSK_LOSS_BPR) {
+            const float x = s0 - s;
+            const float g = inv_norm / (1.f + expf(x));  // sigma(-x)/(B*N) = d loss / d s_neg
+            hsk_row_axpy(acc, g, buf[r]);
+            gsum += g;
+            gv = (lane == j + r) ? g : gv;
+            xv = (lane == j + r) ? x : xv;
+          } else if (LOSS == HSK_LOSS_BCE) {
+            const float g = inv_norm / (1.f + expf(-s));  // sigma(s)/(B*K), label 0
+            hsk_row_axpy(acc, g, buf[r]);
+            gv = (lane == j + r) ? g : gv;
+            xv = (lane == j + r) ? s : xv;
+          } else {
+            const float z = s + ssm_c;
+            if (z > smax) {  // wave-uniform branch: rescale what has been accumulated so far
+              const float f = expf(smax - z);
+              ssum *= f;
+#pragma unroll
+              for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+                for (int q = 0; q < V; ++q) acc.c[cc].v[q] *= f;
+              smax = z;
+            }
+            const float e = expf(z - smax);
+            ssum += e;
+            hsk_row_axpy(acc, e, buf[r]);
+            gv = (lane == j + r) ? z : gv;  // finalised below
+          }
         }
       }
     };
@@ -75,12 +108,32 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
     }
     if (lane < nr) {
       g_s[(long long)b * K + kc + lane] = gv;
-      lsum += (double)hsk_softplus(-xv);
+      if (LOSS == HSK_LOSS_BPR) lsum += (double)hsk_softplus(-xv);
+      if (LOSS == HSK_LOSS_BCE) lsum += (double)hsk_softplus(xv);
     }
   }
-  // positive: d loss / d s_pos = -sum_n sigma(-x_n)/(B*N)
-  const float g0 = -gsum;
-  hsk_row_axpy(acc, g0, r0);
+  float g0;
+  if (LOSS == HSK_LOSS_BPR) {
+    g0 = -gsum;                       // d loss / d s_pos = -sum_n sigma(-x_n)/(B*N)
+    hsk_row_axpy(acc, g0, r0);
+  } else if (LOSS == HSK_LOSS_BCE) {
+    g0 = -inv_norm / (1.f + expf(s0));   // (sigma(s_0) - 1)/(B*K)
+    hsk_row_axpy(acc, g0, r0);
+    if (lane == 0) lsum += (double)hsk_softplus(-s0);
+  } else {
+    // softmax_k = exp(z_k - smax)/ssum;  d loss/d s_k = (softmax_k - [k==0]) / B
+    const float rinv = inv_norm / ssum;
+    g0 = expf(s0 - smax) * rinv - inv_norm;
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc.c[cc].v[q] = fmaf(acc.c[cc].v[q], rinv, -inv_norm * r0.c[cc].v[q]);
+    for (int k = 1 + lane; k < K; k += 64) {   // stored z_k -> gradients (same lanes wrote them)
+      const float z = g_s[(long long)b * K + k];
+      g_s[(long long)b * K + k] = expf(z - smax) * rinv;
+    }
+    if (lane == 0) lsum += (double)(-s0 + smax + logf(ssum));
+  }
   if (lane == 0) g_s[(long long)b * K] = g0;
   // row-sharded user tables: the gradient row goes straight into its slot of the all-to-all send buffer
   hsk_row_store<V, NCH, FULL>(acc, dUb + (long long)(dU_index ? hsk_uniform_i(dU_index[b]) : b) * D, lane, D);

@@ -98,6 +98,25 @@ def bpr_loss_grad(logits: torch.Tensor, need_grad: bool = True):
     return loss, grad
 
 
+LOSS_KINDS = {'bpr': 0, 'bce': 1, 'sampled_softmax': 2}   # HSK_LOSS_* of include/hassaku_hip.h
+
+
+def rec_loss_grad(kind: str, logits: torch.Tensor, log_adjust: float = 0.0, need_grad: bool = True):
+    """Any of the reference's three losses on logits [B, 1+N] -> (loss fp64 [1], grad_logits fp32 [B,K] or None)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(logits, torch.float32, 'logits')
+    if logits.dim() != 2 or logits.shape[1] < 2 or logits.shape[0] < 1:
+        raise ValueError(f'logits must be [B>=1, K>=2], got {tuple(logits.shape)}')
+    B, K = logits.shape
+    loss = torch.empty(1, dtype=torch.float64, device=logits.device)
+    ws = torch.empty(B, dtype=torch.float64, device=logits.device)
+    grad = torch.empty_like(logits) if need_grad else None
+    _lib.check(lib.hsk_rec_loss_grad(LOSS_KINDS[kind], _p(logits), B, K, float(log_adjust), _p(loss), _p(grad), _p(ws),
+                                     _stream()), 'hsk_rec_loss_grad')
+    return loss, grad
+
+
 def mf_backward(user_emb, item_emb, u_idx, i_idx, grad_logits, want_item_bias, want_user_bias, want_global_bias,
                 status=None):
     """Dense parameter gradients (what embedding_dense_backward would give)."""
@@ -167,7 +186,8 @@ class BprMfFusedState:
 
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, seed=0,
-                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=False):
+                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=False,
+                 loss='bpr', log_adjust=0.0):
         _lib.require_gpu()
         self.lib = _lib.load()
         n_users, dim = user_emb.shape
@@ -216,6 +236,11 @@ class BprMfFusedState:
         # exact lazy AdamW on user rows (bit-identical to the dense sweep after flush()); dense when False
         st.lazy_users = 1 if lazy_users else 0
         st.timing_mask = 0
+        if loss not in LOSS_KINDS:
+            raise ValueError(f'unknown loss {loss!r}')
+        if loss == 'bce' and (user_bias is not None or global_bias is not None):
+            raise ValueError('the fused bce step treats user/global bias as gradient-free; use the autograd path')
+        st.loss_kind, st.reserved1, st.ssm_log_adjust = LOSS_KINDS[loss], 0, float(log_adjust)
         st.timing = None
         st.timing_every = 1
         st.timing_now = 0

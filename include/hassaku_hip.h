@@ -31,6 +31,9 @@ enum {
   HSK_ERR_HIP = 3          /* a HIP runtime call failed */
 };
 
+/* loss kinds (hsk_bprmf_state.loss_kind, hsk_rec_loss_grad) */
+enum { HSK_LOSS_BPR = 0, HSK_LOSS_BCE = 1, HSK_LOSS_SSM = 2 };
+
 /* bits of the device-side status word */
 enum {
   HSK_STATUS_BAD_INDEX = 1,       /* an index was outside [0, n) and was clamped */
@@ -68,6 +71,15 @@ int hsk_mf_scores(const float* user_emb, const float* item_emb, const float* ite
  * autograd backward.  ws: device scratch of `batch` doubles.
  */
 int hsk_bpr_loss_grad(const float* logits, int64_t batch, int64_t n_cols,
+                      double* loss, float* grad_logits, double* ws, hsk_stream_t stream);
+
+/*
+ * The same for any of the reference's three losses (train/rec_losses.py:27-53 bce, :56-88 bpr, :91-139
+ * sampled_softmax): kind = HSK_LOSS_*; log_adjust is added to the negatives' logits before the softmax
+ * (log(n_items / neg_train) under uniform sampling, 0 otherwise; ignored by bpr / bce).
+ *   bce: mean over batch*n_cols of BCEWithLogits(logit, [col == 0]);  ssm: mean over batch of -l_0 + logsumexp.
+ */
+int hsk_rec_loss_grad(int32_t kind, const float* logits, int64_t batch, int64_t n_cols, double log_adjust,
                       double* loss, float* grad_logits, double* ws, hsk_stream_t stream);
 
 /*
@@ -153,6 +165,11 @@ typedef struct hsk_bprmf_state {
   /* event-time only every timing_every-th step (<= 1: every step); timing_now is library scratch */
   int32_t timing_every;
   int32_t timing_now;
+  /* recommendation loss of the fused step (train/rec_losses.py): HSK_LOSS_BPR (default, 0), HSK_LOSS_BCE,
+     HSK_LOSS_SSM (sampled softmax; ssm_log_adjust = log(n_items / neg_train) for uniform sampling, else 0) */
+  int32_t loss_kind;
+  int32_t reserved1;
+  double ssm_log_adjust;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;

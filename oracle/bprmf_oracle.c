@@ -59,6 +59,46 @@ double orc_bpr_loss_grad(const float* logits, int64_t B, int64_t K, float* grad 
   return loss * inv;
 }
 
+/* train/rec_losses.py:27-53 -- RecBinaryCrossEntropy: BCEWithLogits(logits.flatten(), labels.flatten()) with fp64
+ * labels (column 0 = 1): fp64 mean over B*K of softplus(-s) for the positive, softplus(s) for a negative;
+ * grad = (sigmoid(s) - y)/(B*K) cast to fp32. */
+double orc_bce_loss_grad(const float* logits, int64_t B, int64_t K, float* grad /* nullable */) {
+  const double inv = 1.0 / ((double)B * (double)K);
+  double loss = 0.0;
+  for (int64_t b = 0; b < B; ++b)
+    for (int64_t k = 0; k < K; ++k) {
+      const double s = (double)logits[b * K + k];
+      const double y = (k == 0) ? 1.0 : 0.0;
+      loss += fmax(s, 0.0) - s * y + log1p(exp(-fabs(s)));
+      if (grad) grad[b * K + k] = (float)((1.0 / (1.0 + exp(-s)) - y) * inv);
+    }
+  return loss * inv;
+}
+
+/* train/rec_losses.py:91-139 -- RecSampledSoftmaxLoss: logits[:,1:] += log_adjust (= log(n_items/neg_train) for
+ * uniform sampling); loss = mean_b( -logits[b,0] + logsumexp(logits[b,:]) ), all in fp32 in the reference;
+ * grad[b,k] = (softmax_k - [k==0]) / B. */
+double orc_ssm_loss_grad(const float* logits, int64_t B, int64_t K, double log_adjust, float* grad /* nullable */) {
+  double loss = 0.0;
+  const float adj = (float)log_adjust;
+  for (int64_t b = 0; b < B; ++b) {
+    double mx = -INFINITY;
+    for (int64_t k = 0; k < K; ++k) {
+      const double z = (double)(k == 0 ? logits[b * K] : logits[b * K + k] + adj);
+      if (z > mx) mx = z;
+    }
+    double sum = 0.0;
+    for (int64_t k = 0; k < K; ++k) sum += exp((double)(k == 0 ? logits[b * K] : logits[b * K + k] + adj) - mx);
+    loss += -(double)logits[b * K] + mx + log(sum);
+    if (grad)
+      for (int64_t k = 0; k < K; ++k) {
+        const double z = (double)(k == 0 ? logits[b * K] : logits[b * K + k] + adj);
+        grad[b * K + k] = (float)((exp(z - mx) / sum - (k == 0 ? 1.0 : 0.0)) / (double)B);
+      }
+  }
+  return loss / (double)B;
+}
+
 /* autograd of orc_mf_scores (train/trainer.py:146; embedding_dense_backward scatter-add):
  * dU[u_b] += sum_k g[b,k] I[i_bk]; dI[i_bk] += g[b,k] U[u_b]; dIb[i_bk] += g[b,k];
  * dUb[u_b] += sum_k g[b,k]; dgb += sum g.  Outputs are dense and fully overwritten. */

@@ -124,6 +124,60 @@ def gen_g1():
         print('g1', tag, 'loss3', float(fx['s3.loss']))
 
 
+def gen_g6():
+    """bce and sampled_softmax on the same scorer (train/rec_losses.py:27-53,91-139): 3 AdamW steps each."""
+    from algorithms.sgd_alg import SGDMatrixFactorization
+    from train.rec_losses import RecBinaryCrossEntropy, RecSampledSoftmaxLoss
+    cases = [
+        ('bce_d32_item', 'bce', 32, 40, 130, 16, 7, False, True, False),
+        ('bce_d32_all', 'bce', 32, 40, 130, 16, 7, True, True, True),
+        ('ssm_d32_item', 'sampled_softmax', 32, 40, 130, 16, 7, False, True, False),
+        ('ssm_d402_all', 'sampled_softmax', 402, 24, 110, 8, 4, True, True, True),
+    ]
+    lr, wd = 3e-4, 4e-5
+    for tag, kind, D, U, I, B, N, ub, ib, gb in cases:
+        torch.manual_seed(64)
+        model = SGDMatrixFactorization(U, I, D, ub, ib, gb)
+        with torch.no_grad():   # larger logits than the 0.1/D init gives, so the softmax / sigmoid are not flat
+            model.user_embeddings.weight.mul_(20. * D ** 0.5)
+            model.item_embeddings.weight.mul_(20. * D ** 0.5)
+        loss_fn = RecBinaryCrossEntropy() if kind == 'bce' else RecSampledSoftmaxLoss(I, 'uniform', N)
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+        rng = np.random.RandomState(11)
+        fx = {'lr': lr, 'wd': wd, 'n_users': U, 'n_items': I, 'dim': D, 'n_neg': N,
+              'use_user_bias': ub, 'use_item_bias': ib, 'use_global_bias': gb,
+              'log_adjust': float(np.log(I / N)) if kind == 'sampled_softmax' else 0.0}
+        for k, v in state_np(model).items():
+            fx['init.' + k] = v
+        for step in range(1, 4):
+            u = torch.from_numpy(rng.randint(0, U, size=B).astype(np.int64))
+            i = torch.from_numpy(rng.randint(0, I, size=(B, 1 + N)).astype(np.int64))
+            labels = torch.zeros((B, 1 + N), dtype=torch.float64)
+            labels[:, 0] = 1.
+            out = model(u, i)
+            out.retain_grad()
+            fx[f's{step}.logits'] = out.detach().numpy().copy()    # before the loss touches them (ssm adds in place)
+            loss = loss_fn.compute_loss(out, labels)
+            total = loss + model.get_and_reset_other_loss()['reg_loss']
+            total.backward()
+            fx[f's{step}.u_idx'] = u.numpy()
+            fx[f's{step}.i_idx'] = i.numpy()
+            fx[f's{step}.loss'] = np.array(loss.item(), dtype=np.float64)
+            if step == 1:
+                fx['s1.grad_logits'] = out.grad.numpy().copy()
+                for name, p in model.named_parameters():
+                    fx['s1.grad.' + name] = p.grad.numpy().copy()
+            opt.step()
+            opt.zero_grad()
+            if step in (1, 3):
+                for k, v in state_np(model).items():
+                    fx[f's{step}.param.' + k] = v
+                for k, v in opt_state_np(model, opt).items():
+                    fx[f's{step}.' + k] = v
+        np.savez_compressed(os.path.join(OUT, f'g6_{tag}.npz'), **fx)
+        print('g6', tag, 'loss1', float(fx['s1.loss']), 'loss3', float(fx['s3.loss']), loss.dtype)
+
+
 def toy_dataset(tmp, n_users=64, n_items=150, n_inter=2600, n_groups=2, seed=3):
     from hassaku_amd.data.synthetic import generate, write_csv_dataset
     data = generate(n_users, n_items, n_inter, seed=seed, n_groups=n_groups)
@@ -270,3 +324,4 @@ if __name__ == '__main__':
     gen_g3()
     gen_g4()
     gen_g5()
+    gen_g6()

@@ -71,6 +71,25 @@ def bpr_loss_grad(logits, need_grad=True):
     return float(loss), grad
 
 
+def rec_loss_grad(kind, logits, log_adjust=0.0, need_grad=True):
+    """kind in {'bpr','bce','sampled_softmax'} (train/rec_losses.py:27-139) -> (loss, grad wrt logits)"""
+    if kind == 'bpr':
+        return bpr_loss_grad(logits, need_grad)
+    logits = _f32(logits)
+    B, K = logits.shape
+    grad = np.empty_like(logits) if need_grad else None
+    L = lib()
+    L.orc_bce_loss_grad.restype = c_double
+    L.orc_ssm_loss_grad.restype = c_double
+    if kind == 'bce':
+        loss = L.orc_bce_loss_grad(_p(logits), c_int64(B), c_int64(K), _p(grad))
+    elif kind == 'sampled_softmax':
+        loss = L.orc_ssm_loss_grad(_p(logits), c_int64(B), c_int64(K), c_double(log_adjust), _p(grad))
+    else:
+        raise ValueError(kind)
+    return float(loss), grad
+
+
 def mf_backward(U, I, u_idx, i_idx, g, item_bias=True, user_bias=False, global_bias=False):
     """autograd backward of mf_scores -> dense grads"""
     U, I, g = _f32(U), _f32(I), _f32(g)
@@ -101,7 +120,8 @@ class MfOracleTrainer:
     s_pos - s_neg; the reference's ~1e-9 autograd noise there is amplified by Adam and is not part
     of the contract -- SURVEY.md section 7, hard part 2)."""
 
-    def __init__(self, U, I, Ib=None, Ub=None, gb=None, lr=1e-3, wd=0.0):
+    def __init__(self, U, I, Ib=None, Ub=None, gb=None, lr=1e-3, wd=0.0, loss='bpr', log_adjust=0.0):
+        self.loss, self.log_adjust = loss, log_adjust
         self.P = {'user_emb': _f32(U).copy(), 'item_emb': _f32(I).copy()}
         if Ib is not None:
             self.P['item_bias'] = _f32(Ib).reshape(-1).copy()
@@ -121,9 +141,13 @@ class MfOracleTrainer:
     def step(self, u_idx, i_idx):
         P = self.P
         logits = self.forward(u_idx, i_idx)
-        loss, g = bpr_loss_grad(logits)
-        gU, gI, gIb, _, _ = mf_backward(P['user_emb'], P['item_emb'], u_idx, i_idx, g, item_bias='item_bias' in P)
-        grads = {'user_emb': gU, 'item_emb': gI, 'item_bias': gIb, 'user_bias': None, 'global_bias': None}
+        loss, g = rec_loss_grad(self.loss, logits, self.log_adjust)
+        # bpr / sampled_softmax: the user and global bias cancel in the loss (zero gradient by definition);
+        # bce sees every logit on its own, so they do receive gradient
+        bce = self.loss == 'bce'
+        gU, gI, gIb, gUb, ggb = mf_backward(P['user_emb'], P['item_emb'], u_idx, i_idx, g, item_bias='item_bias' in P,
+                                            user_bias=bce and 'user_bias' in P, global_bias=bce and 'global_bias' in P)
+        grads = {'user_emb': gU, 'item_emb': gI, 'item_bias': gIb, 'user_bias': gUb, 'global_bias': ggb}
         self.t += 1
         for k in P:
             adamw_step(P[k], grads[k], self.M[k], self.V[k], self.lr, self.wd, self.t)
