@@ -36,6 +36,7 @@ class HskBprmfState(ctypes.Structure):
         ('timing', c_void_p), ('aux', c_void_p),
         ('timing_every', c_int32), ('timing_now', c_int32),
         ('loss_kind', c_int32), ('reserved1', c_int32), ('ssm_log_adjust', c_double),
+        ('alias_prob', c_void_p), ('alias_idx', c_void_p),
         ('loss_out', c_void_p), ('status', c_void_p),
     ]
 
@@ -69,6 +70,8 @@ SIGNATURES = {
     'hsk_adamw_dense': (c_int, [c_void_p] * 4 + [c_int64] + [c_double] * 5 + [c_int64, c_void_p]),
     'hsk_sample_negatives_uniform': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                              c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    'hsk_sample_negatives_alias': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_int64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     'hsk_bprmf_workspace_bytes': (c_int64, [c_int64] * 5),
     'hsk_bprmf_init_workspace': (c_int, [POINTER(HskBprmfState), c_void_p]),
     'hsk_bprmf_train_step': (c_int, [POINTER(HskBprmfState), c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

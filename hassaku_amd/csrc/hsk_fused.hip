@@ -116,6 +116,8 @@ static int hsk_check_state(const hsk_bprmf_state* st) {
   HSK_REQUIRE(st->step >= 0 && st->step < 0x7ffffff0, HSK_ERR_UNSUPPORTED, "step counter out of range");
   HSK_REQUIRE(st->loss_kind >= HSK_LOSS_BPR && st->loss_kind <= HSK_LOSS_SSM, HSK_ERR_INVALID, "unknown loss_kind %d",
               st->loss_kind);
+  HSK_REQUIRE((st->alias_prob == nullptr) == (st->alias_idx == nullptr), HSK_ERR_INVALID,
+              "alias table needs both alias_prob and alias_idx");
   return HSK_OK;
 }
 
@@ -430,7 +432,7 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
                                 st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
                                 st->csr_indices, (int)st->n_items, st->seed, (uint64_t)st->step, w.u32, w.it32,
-                                w.owner, w.cnt, st->status));
+                                w.owner, w.cnt, st->status, 0, hsk_alias{st->alias_prob, st->alias_idx}));
   HSK_LAUNCH_CHECK();
   return hsk_run_step(st, w, batch, n_neg + 1, stream);
 }
@@ -453,6 +455,24 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   const int64_t total = batch * n_cols;
   k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
                                                                                       u_out, i_out);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+extern "C" int hsk_sample_negatives_alias(const int64_t* csr_indptr, const int32_t* csr_indices, int64_t n_users,
+                                          int64_t n_items, const float* alias_prob, const int32_t* alias_idx,
+                                          const int64_t* u_idx, int64_t batch, int64_t n_neg, uint64_t seed,
+                                          uint64_t stream_id, int64_t* neg_out, int32_t* status,
+                                          hsk_stream_t stream_) {
+  HSK_REQUIRE(csr_indptr && csr_indices && u_idx && neg_out && alias_prob && alias_idx, HSK_ERR_INVALID,
+              "NULL pointer argument");
+  HSK_REQUIRE(n_users > 0 && n_items > 0 && n_items < 0x7fffffff && n_users < 0x7fffffff, HSK_ERR_INVALID,
+              "bad n_users / n_items");
+  HSK_REQUIRE(batch >= 0 && n_neg >= 1, HSK_ERR_INVALID, "bad batch / n_neg");
+  if (batch == 0) return HSK_OK;
+  k_sample_negatives<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, (hipStream_t)stream_>>>(
+      csr_indptr, csr_indices, (int)n_users, (int)n_items, u_idx, (int)batch, (int)n_neg, seed, stream_id, neg_out,
+      status, hsk_alias{alias_prob, alias_idx});
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }

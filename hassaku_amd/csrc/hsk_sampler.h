@@ -44,9 +44,18 @@ __device__ __forceinline__ bool hsk_row_has(const int32_t* __restrict__ idx, lon
 
 // One draw for slot (b, n): Philox counter = (b, n, stream_lo, (stream_hi<<16) | block), 4 attempts per
 // block; exact uniform integer via Lemire's multiply-shift with rejection of the biased zone.
+// With an alias table (alias_prob != NULL; Walker/Vose, built on the host from pop_distribution^squash --
+// NegativeSampler._neg_sample_popular, data/dataloader.py:59-64) a draw uses two words: a uniform column and a
+// uniform float deciding between the column and its alias, i.e. 2 attempts per block, same rejection rule.
+struct hsk_alias {
+  const float* prob;     // NULL: uniform sampling
+  const int32_t* alias;
+};
+
 __device__ __forceinline__ int hsk_draw_negative(const int32_t* __restrict__ csr_indices, long long row_lo,
                                                  long long row_hi, uint32_t n_items, uint32_t b, uint32_t n,
-                                                 uint64_t seed, uint64_t stream_id, int32_t* status) {
+                                                 uint64_t seed, uint64_t stream_id, int32_t* status,
+                                                 hsk_alias at = hsk_alias{nullptr, nullptr}) {
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const uint32_t thresh = (uint32_t)(-(int32_t)n_items) % n_items;  // 2^32 mod n_items
   int last = 0;
@@ -58,6 +67,19 @@ __device__ __forceinline__ int hsk_draw_negative(const int32_t* __restrict__ csr
     ctr.w = ((uint32_t)(stream_id >> 32) << 16) | (blk & 0xffffu);
     const hsk_u32x4 r = hsk_philox4x32_10(ctr, k0, k1);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+    if (at.prob) {
+#pragma unroll
+      for (int a = 0; a < 4; a += 2) {
+        const uint64_t m = (uint64_t)rr[a] * (uint64_t)n_items;
+        if ((uint32_t)m < thresh) continue;
+        const int col = (int)(m >> 32);
+        const float u01 = (float)(rr[a + 1] >> 8) * (1.0f / 16777216.0f);
+        const int cand = (u01 < at.prob[col]) ? col : at.alias[col];
+        last = cand;
+        if (!hsk_row_has(csr_indices, row_lo, row_hi, cand)) return cand;
+      }
+      continue;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const uint64_t m = (uint64_t)rr[a] * (uint64_t)n_items;
@@ -80,7 +102,8 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
                                                      uint64_t seed, uint64_t stream_id, int* __restrict__ u32,
                                                      int* __restrict__ it32,
                                                      int* __restrict__ owner, int* __restrict__ cnt,
-                                                     int32_t* status, int b_offset = 0) {
+                                                     int32_t* status, int b_offset = 0,
+                                                     hsk_alias at = hsk_alias{nullptr, nullptr}) {
   // b_offset: position of this rank's slice inside the global batch.  The RNG counter uses the GLOBAL batch
   // position, so N ranks with slices of B draw exactly what one device draws for a batch of N*B.
   // owner == NULL: no owner map (row-sharded user tables build it on the owning rank instead).
@@ -96,7 +119,7 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
   int* row = it32 + (long long)b * K;
   for (int n = lane; n < n_neg; n += 64) {
     const int neg = hsk_draw_negative(csr_indices, lo, hi, (uint32_t)n_items, (uint32_t)(b + b_offset), (uint32_t)n,
-                                      seed, stream_id, status);
+                                      seed, stream_id, status, at);
     row[1 + n] = neg;
   }
   if (lane == 0) {
@@ -114,7 +137,8 @@ __global__ __launch_bounds__(256) void k_sample_negatives(const int64_t* __restr
                                                           const int32_t* __restrict__ csr_indices, int n_users,
                                                           int n_items, const int64_t* __restrict__ u_idx, int B,
                                                           int n_neg, uint64_t seed, uint64_t stream_id,
-                                                          int64_t* __restrict__ out, int32_t* status) {
+                                                          int64_t* __restrict__ out, int32_t* status,
+                                                          hsk_alias at = hsk_alias{nullptr, nullptr}) {
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
@@ -123,5 +147,5 @@ __global__ __launch_bounds__(256) void k_sample_negatives(const int64_t* __restr
   const long long lo = csr_indptr[u], hi = csr_indptr[u + 1];
   for (int n = lane; n < n_neg; n += 64)
     out[(long long)b * n_neg + n] = hsk_draw_negative(csr_indices, lo, hi, (uint32_t)n_items, (uint32_t)b,
-                                                      (uint32_t)n, seed, stream_id, status);
+                                                      (uint32_t)n, seed, stream_id, status, at);
 }

@@ -1,6 +1,7 @@
 """Training loader with on-device negative sampling -- drop-in for data/dataloader.py:17-129.
 
-The reference draws negatives on the host inside the DataLoader's collate_fn (numpy randint + a per-row
+Strategies: 'uniform' and 'popular' (alias table over pop_distribution ** squashing factor).  The reference draws
+negatives on the host inside the DataLoader's collate_fn (numpy randint + a per-row
 scipy CSR slice + np.isin, repeated until nothing collides) and ships int64/float64 tensors to the
 device every step.  Here the epoch permutation, the positives and the negatives all live in HBM:
 `hsk_sample_negatives_uniform` (Philox4x32-10, rejection against the user's sorted CSR row) produces the
@@ -34,8 +35,6 @@ class NegativeSampler(InteractionSampler):
         assert neg_sampling_strategy in ['uniform', 'popular'], \
             f'<{neg_sampling_strategy}> is not a valid negative sampling strategy!'
         assert squashing_factor_pop_sampling >= 0, 'Squashing factor for popularity sampling should be positive!'
-        if neg_sampling_strategy == 'popular':
-            raise NotImplementedError("train_neg_strategy 'popular' is not on the HIP path yet (SURVEY.md 8f rank 2)")
         self.dataset = train_dataset
         self.n_neg = n_neg
         self.neg_sampling_strategy = neg_sampling_strategy
@@ -43,7 +42,24 @@ class NegativeSampler(InteractionSampler):
         self.n_items = train_dataset.n_items
         self.pop_distribution = train_dataset.pop_distribution.copy()
         self.name = 'NegativeSampler'
+        self._alias_host = None
+        self._alias_dev = {}
         logging.info('Built %s n_neg=%d strategy=%s', self.name, n_neg, neg_sampling_strategy)
+
+    def alias(self, device):
+        """Device alias table (prob, idx) of pop_distribution ** squashing_factor for 'popular' sampling
+        (data/dataloader.py:59-64 of the reference: p = pop^alpha / sum), None for 'uniform'."""
+        if self.neg_sampling_strategy != 'popular':
+            return None
+        if self._alias_host is None:
+            import numpy as np
+            p = np.power(self.pop_distribution, self.squashing_factor_pop_sampling)
+            self._alias_host = hip_ops.build_alias_table(p / p.sum())
+        key = str(device)
+        if key not in self._alias_dev:
+            prob, idx = self._alias_host
+            self._alias_dev[key] = (torch.from_numpy(prob).to(device), torch.from_numpy(idx).to(device))
+        return self._alias_dev[key]
 
 
 class TrainDataLoader:
@@ -106,7 +122,8 @@ class TrainDataLoader:
             u = arrays['coo_user'][sel].to(torch.int64)
             pos = arrays['coo_item'][sel].to(torch.int64)
             neg = hip_ops.sample_negatives_uniform(arrays['csr_indptr'], arrays['csr_indices'], n_items, u, n_neg,
-                                                   seed=self.seed, stream_id=(epoch << 32) | step, status=status)
+                                                   seed=self.seed, stream_id=(epoch << 32) | step, status=status,
+                                                   alias=self.interaction_sampler.alias(self.device))
             items = torch.cat([pos[:, None], neg], dim=1)
             yield u, items, self._label_tensor(nb, 1 + n_neg)
         hip_ops.raise_on_status(status, 'TrainDataLoader')

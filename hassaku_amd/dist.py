@@ -106,7 +106,7 @@ class ShardedBprMf:
 
     def __init__(self, comm: Comm, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  batch, n_neg, csr_indptr, csr_indices, coo_user, coo_item, seed=0, beta1=ADAM_BETA1,
-                 beta2=ADAM_BETA2, eps=ADAM_EPS, capacity: Optional[int] = None, loss='bpr', log_adjust=0.0):
+                 beta2=ADAM_BETA2, eps=ADAM_EPS, capacity: Optional[int] = None, loss='bpr', log_adjust=0.0, alias=None):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.comm = comm
@@ -178,6 +178,8 @@ class ShardedBprMf:
         if loss == 'bce' and (user_bias is not None or global_bias is not None):
             raise ValueError('the fused bce step treats user/global bias as gradient-free')
         st.loss_kind, st.reserved1, st.ssm_log_adjust = hip_ops.LOSS_KINDS[loss], 0, float(log_adjust)
+        self.alias = alias
+        st.alias_prob, st.alias_idx = (None, None) if alias is None else (_p(alias[0]), _p(alias[1]))
         st.loss_out, st.status = _p(self.loss_out), _p(self.status)
         mp.world, mp.rank = W, r
         mp.n_users_global, mp.capacity = U, C

@@ -158,8 +158,30 @@ def adamw_dense(p, g, m, v, lr, wd, step, beta1=ADAM_BETA1, beta2=ADAM_BETA2, ep
                'hsk_adamw_dense')
 
 
-def sample_negatives_uniform(csr_indptr, csr_indices, n_items, u_idx, n_neg, seed, stream_id=0, status=None):
-    """neg[b,n] ~ U{[0,n_items) minus the CSR row of u_b}.  -> int64 [B, n_neg]."""
+def build_alias_table(p):
+    """Walker/Vose alias table of a discrete distribution p (host, float64) -> (prob float32 [n], alias int32 [n]):
+    draw a uniform column j, keep j with probability prob[j], else take alias[j]."""
+    import numpy as np
+    p = np.asarray(p, dtype=np.float64)
+    n = len(p)
+    if n == 0 or p.min() < 0 or not np.isfinite(p).all() or p.sum() <= 0:
+        raise ValueError('alias table needs a non-empty, non-negative, finite distribution')
+    scaled = p / p.sum() * n
+    prob, alias = np.ones(n, dtype=np.float64), np.arange(n, dtype=np.int32)
+    small = [i for i in range(n) if scaled[i] < 1.0]
+    large = [i for i in range(n) if scaled[i] >= 1.0]
+    while small and large:
+        s, g = small.pop(), large.pop()
+        prob[s], alias[s] = scaled[s], g
+        scaled[g] -= 1.0 - scaled[s]
+        (small if scaled[g] < 1.0 else large).append(g)
+    return prob.astype(np.float32), alias
+
+
+def sample_negatives_uniform(csr_indptr, csr_indices, n_items, u_idx, n_neg, seed, stream_id=0, status=None,
+                             alias=None):
+    """neg[b,n] ~ U{[0,n_items) minus the CSR row of u_b}  (alias=None), or the item distribution of the alias table
+    (alias = (prob f32 [I], idx i32 [I]) device tensors) restricted the same way.  -> int64 [B, n_neg]."""
     _lib.require_gpu()
     lib = _lib.load()
     _chk(csr_indptr, torch.int64, 'csr_indptr')
@@ -168,9 +190,17 @@ def sample_negatives_uniform(csr_indptr, csr_indices, n_items, u_idx, n_neg, see
     n_users = csr_indptr.numel() - 1
     B = u_idx.numel()
     out = torch.empty((B, n_neg), dtype=torch.int64, device=u_idx.device)
-    _lib.check(lib.hsk_sample_negatives_uniform(_p(csr_indptr), _p(csr_indices), n_users, n_items, _p(u_idx), B, n_neg,
-                                                seed, stream_id, _p(out), _p(status), _stream()),
-               'hsk_sample_negatives_uniform')
+    if alias is None:
+        _lib.check(lib.hsk_sample_negatives_uniform(_p(csr_indptr), _p(csr_indices), n_users, n_items, _p(u_idx), B,
+                                                    n_neg, seed, stream_id, _p(out), _p(status), _stream()),
+                   'hsk_sample_negatives_uniform')
+    else:
+        prob, idx = alias
+        _chk(prob, torch.float32, 'alias prob', (n_items,))
+        _chk(idx, torch.int32, 'alias idx', (n_items,))
+        _lib.check(lib.hsk_sample_negatives_alias(_p(csr_indptr), _p(csr_indices), n_users, n_items, _p(prob), _p(idx),
+                                                  _p(u_idx), B, n_neg, seed, stream_id, _p(out), _p(status),
+                                                  _stream()), 'hsk_sample_negatives_alias')
     return out
 
 
@@ -187,7 +217,7 @@ class BprMfFusedState:
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, seed=0,
                  csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=False,
-                 loss='bpr', log_adjust=0.0):
+                 loss='bpr', log_adjust=0.0, alias=None):
         _lib.require_gpu()
         self.lib = _lib.load()
         n_users, dim = user_emb.shape
@@ -241,6 +271,11 @@ class BprMfFusedState:
         if loss == 'bce' and (user_bias is not None or global_bias is not None):
             raise ValueError('the fused bce step treats user/global bias as gradient-free; use the autograd path')
         st.loss_kind, st.reserved1, st.ssm_log_adjust = LOSS_KINDS[loss], 0, float(log_adjust)
+        self.alias = alias   # (prob f32 [I], idx i32 [I]) for train_neg_strategy 'popular', None = uniform
+        if alias is not None:
+            _chk(alias[0], torch.float32, 'alias prob', (n_items,))
+            _chk(alias[1], torch.int32, 'alias idx', (n_items,))
+        st.alias_prob, st.alias_idx = (None, None) if alias is None else (_p(alias[0]), _p(alias[1]))
         st.timing = None
         st.timing_every = 1
         st.timing_now = 0

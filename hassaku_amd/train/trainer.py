@@ -91,6 +91,7 @@ class Trainer:
         if isinstance(loader, TrainDataLoader):
             kw = loader.dataset.device_arrays(torch.device(self.device))
             max_batch, n_neg, seed = loader.batch_size, loader.interaction_sampler.n_neg, loader.seed
+            kw['alias'] = loader.interaction_sampler.alias(torch.device(self.device))
         else:
             max_batch, n_neg = conf['train_batch_size'], conf['neg_train']
             seed = conf['running_settings'].get('seed', 64)
@@ -106,7 +107,8 @@ class Trainer:
         arrays = loader.dataset.device_arrays(torch.device(self.device))
         return ShardedBprMf(self.comm, user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd,
                             batch=loader.batch_size, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed,
-                            loss=self.rec_loss.kind, log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0), **arrays)
+                            loss=self.rec_loss.kind, log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0),
+                            alias=loader.interaction_sampler.alias(torch.device(self.device)), **arrays)
 
     def _sync_model_from_shards(self):
         """Assemble the row-sharded user table into the model's parameters (every rank), e.g. before saving."""

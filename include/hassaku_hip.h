@@ -118,6 +118,19 @@ int hsk_sample_negatives_uniform(const int64_t* csr_indptr, const int32_t* csr_i
                                  uint64_t seed, uint64_t stream_id,
                                  int64_t* neg_out, int32_t* status, hsk_stream_t stream);
 
+/*
+ * The same with negatives drawn from an item distribution p (train_neg_strategy 'popular':
+ * NegativeSampler._neg_sample_popular, data/dataloader.py:59-64, p = pop_distribution^squash normalised), given
+ * as a Walker alias table built on the host: column j keeps itself with probability alias_prob[j], else
+ * alias_idx[j].  Still rejected against the user's CSR row, i.e. p restricted to the items the user has not seen.
+ */
+int hsk_sample_negatives_alias(const int64_t* csr_indptr, const int32_t* csr_indices,
+                               int64_t n_users, int64_t n_items,
+                               const float* alias_prob, const int32_t* alias_idx,
+                               const int64_t* u_idx, int64_t batch, int64_t n_neg,
+                               uint64_t seed, uint64_t stream_id,
+                               int64_t* neg_out, int32_t* status, hsk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused BPR-MF AdamW training step (the hot path of Trainer.fit, train/trainer.py:128-148)
  * ------------------------------------------------------------------------------------------ */
@@ -170,6 +183,10 @@ typedef struct hsk_bprmf_state {
   int32_t loss_kind;
   int32_t reserved1;
   double ssm_log_adjust;
+  /* negative sampling law of the device sampler: NULL = uniform; otherwise a Walker alias table over the items
+     (alias_prob float[I], alias_idx int32[I]) = train_neg_strategy 'popular' (data/dataloader.py:59-64) */
+  const float* alias_prob;
+  const int32_t* alias_idx;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;

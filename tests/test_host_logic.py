@@ -239,8 +239,7 @@ def test_train_loader_lengths_and_sampler_validation(toy_dir):
         NegativeSampler(ds, 0)
     with pytest.raises(AssertionError):
         NegativeSampler(ds, 3, 'zipf')
-    with pytest.raises(NotImplementedError):
-        NegativeSampler(ds, 3, 'popular')
+    assert NegativeSampler(ds, 3, 'popular').neg_sampling_strategy == 'popular'
     with pytest.raises(ValueError):
         TrainDataLoader(object(), ds, batch_size=8)
 
