@@ -387,10 +387,13 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
     HSK_STAGE(HSK_STAGE_ITEM, hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, st->user_emb, w.u32, (int)K, c, nullptr,
                                                                           nullptr, stream));
     if (st->lazy_users) {
-      HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(
+      // + one workgroup for the loss reduction / global bias (no separate finish launch in lazy mode)
+      const hsk_finish_args fin = {w.loss_b, (int)B, inv_bn_d, st->loss_out, st->global_bias, st->m_global_bias,
+                                   st->v_global_bias};
+      HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>(
                                     st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
                                     st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,
-                                    (int)st->step, c)));
+                                    (int)st->step, c, fin)));
     } else {
       HSK_STAGE(HSK_STAGE_USER, (k_user_update<V, NCH, FULL, 0><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
                                     st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
@@ -400,7 +403,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
   });
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
-  {
+  if (!st->lazy_users) {
     hipStream_t stream = aux ? aux->side : main_stream;
     HSK_STAGE(HSK_STAGE_FINISH, k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out,
                                                                        st->global_bias, st->m_global_bias,
@@ -410,6 +413,9 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
       HSK_HIP(hipEventRecord(aux->ev_join, stream));
       HSK_HIP(hipStreamWaitEvent(main_stream, aux->ev_join, 0));
     }
+  } else if (aux) {
+    HSK_HIP(hipEventRecord(aux->ev_join, aux->side));
+    HSK_HIP(hipStreamWaitEvent(main_stream, aux->ev_join, 0));
   }
   if (st->lazy_users && (st->step % HSK_FLUSH_EVERY) == 0) {
     int frc = 0;

@@ -42,6 +42,8 @@ __device__ __forceinline__ bool hsk_row_has(const int32_t* __restrict__ idx, lon
   return (l < hi) && (idx[l] == key);
 }
 
+#define HSK_SAMPLER_LDS_ROW 1024   // positives of one user staged in LDS per wave (longer rows are searched in HBM)
+
 // One draw for slot (b, n): Philox counter = (b, n, stream_lo, (stream_hi<<16) | block), 4 attempts per
 // block; exact uniform integer via Lemire's multiply-shift with rejection of the biased zone.
 // With an alias table (alias_prob != NULL; Walker/Vose, built on the host from pop_distribution^squash --
@@ -117,9 +119,19 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
   const long long lo = csr_indptr[u], hi = csr_indptr[u + 1];
   const int K = n_neg + 1;
   int* row = it32 + (long long)b * K;
+  // stage the user's sorted positives in LDS: the rejection test is a ~7-step binary search per draw, and as
+  // dependent global loads that chain (not the RNG) is what the sampler spends its time on
+  __shared__ int32_t lds_row[4][HSK_SAMPLER_LDS_ROW];
+  const int len = (int)(hi - lo);
+  const bool staged = len <= HSK_SAMPLER_LDS_ROW;
+  if (staged) {
+    for (int j = lane; j < len; j += 64) lds_row[wave][j] = csr_indices[lo + j];
+    __builtin_amdgcn_wave_barrier();
+  }
+  const int32_t* set = staged ? lds_row[wave] : csr_indices + lo;
   for (int n = lane; n < n_neg; n += 64) {
-    const int neg = hsk_draw_negative(csr_indices, lo, hi, (uint32_t)n_items, (uint32_t)(b + b_offset), (uint32_t)n,
-                                      seed, stream_id, status, at);
+    const int neg = hsk_draw_negative(set, 0, len, (uint32_t)n_items, (uint32_t)(b + b_offset), (uint32_t)n, seed,
+                                      stream_id, status, at);
     row[1 + n] = neg;
   }
   if (lane == 0) {

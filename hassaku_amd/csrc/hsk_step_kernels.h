@@ -398,7 +398,47 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
   }
 }
 
-// Lazy mode, after the gradients: the owner applies step `step` to its (already current) row.
+// Tail work of a step that rides on the last launch as one extra workgroup (saves a dependent launch): deterministic
+// fp64 tree sum of the per-positive loss terms and the zero-gradient AdamW step of the global bias.
+struct hsk_finish_args {
+  const double* loss_b;   // NULL: nothing to do
+  int n;
+  double inv_norm;
+  double* loss_out;
+  float* gb;
+  float* mgb;
+  float* vgb;
+};
+
+__device__ __forceinline__ void hsk_finish_block(const hsk_finish_args& f, const hsk_adamw_consts& c) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int i = t; i < f.n; i += 256) s += f.loss_b[i];
+  red[t] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (t < off) red[t] += red[t + off];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double loss = red[0] * f.inv_norm;
+    if (f.loss_out) {
+      f.loss_out[0] = loss;
+      f.loss_out[1] += loss;
+    }
+    if (f.gb) {
+      float p = f.gb[0], m = f.mgb[0], v = f.vgb[0];
+      hsk_adamw_update(p, m, v, 0.f, c);
+      f.gb[0] = p;
+      f.mgb[0] = m;
+      f.vgb[0] = v;
+    }
+  }
+}
+
+// Lazy mode, after the gradients: the owner applies step `step` to its (already current) row.  One extra workgroup
+// (blockIdx == ceil(B/4)) runs hsk_finish_block when `fin.loss_b` is set.
 template <int V, int NCH, bool FULL>
 __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw, float* __restrict__ mU,
                                                           float* __restrict__ vU, float* __restrict__ Ub,
@@ -406,7 +446,13 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
                                                           const float* __restrict__ dUb, const int* __restrict__ u32,
                                                           int* __restrict__ owner, int* __restrict__ cnt,
                                                           int* __restrict__ last_step, int B, int D, int step,
-                                                          hsk_adamw_consts c) {
+                                                          hsk_adamw_consts c,
+                                                          hsk_finish_args fin = hsk_finish_args{nullptr, 0, 0.0, nullptr,
+                                                                                                nullptr, nullptr, nullptr}) {
+  if (fin.loss_b && blockIdx.x == (unsigned)((B + 3) / 4)) {
+    hsk_finish_block(fin, c);
+    return;
+  }
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
