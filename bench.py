@@ -133,7 +133,7 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU-baseline work (0 = skip)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' "
                     "stages collectives through the host and lets several ranks share one GPU: functional rehearsal only)")
-    ap.add_argument('--overlap', action='store_true', help='item sort + loss reduction on a side stream')
+    ap.add_argument('--no-prefetch', action='store_true', help='do not prepare (sample + sort) the next batch on a side stream during the current step')
     ap.add_argument('--dense-users', action='store_true', help='dense AdamW sweep over the user table every step')
     ap.add_argument('--time-all-stages', action='store_true', help='event-time every stage (perturbs the step time)')
     args = ap.parse_args()
@@ -163,7 +163,7 @@ def main():
     nnz = data.train.shape[0]
     comm = None
     if world == 1:
-        st, csr = build_state(data, D, B, N, device, overlap=args.overlap, lazy_users=not args.dense_users)
+        st, csr = build_state(data, D, B, N, device, overlap=not args.no_prefetch, lazy_users=not args.dense_users)
     else:
         st, csr, comm = build_sharded_state(data, D, B, N, device)
 
@@ -178,6 +178,8 @@ def main():
         for s in range(n):
             start = ((first + s) % n_batches) * B * world        # global batch = world * B positives (weak scaling)
             if world == 1:
+                if s + 1 < n:   # the epoch loop knows its next batch: let this step prepare it on the side stream
+                    st.hint_next(order, ((first + s + 1) % n_batches) * B, B, N)
                 st.step_sampled(order, start, B, N)
             else:
                 st.step_sampled(order, start)

@@ -82,6 +82,7 @@ SIGNATURES = {
     'hsk_timing_collect': (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     'hsk_aux_create': (c_void_p, []),
     'hsk_aux_destroy': (None, [c_void_p]),
+    'hsk_bprmf_hint_next': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
     'hsk_mp_prep': (c_int, [POINTER(HskBprmfMp), c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     'hsk_mp_serve': (c_int, [POINTER(HskBprmfMp), c_void_p]),
     'hsk_mp_compute': (c_int, [POINTER(HskBprmfMp), c_void_p]),

@@ -15,6 +15,7 @@
 #include "hsk_item_sliced.h"
 #include <stdlib.h>
 
+#include <utility>
 #include <vector>
 
 #define HSK_ADAM_TAB_LEN 65536   // per-step (step_size, bc2_sqrt) table for the lazy replay
@@ -39,8 +40,28 @@ struct hsk_ws {
   float* dUb;
   double* loss_b;
   float2* adam_tab;
+  // second set of the per-batch buffers: the next batch is sampled and sorted into it while this one trains
+  int *u32_b, *it32_b, *perm_b, *hist_b, *btot_b, *bstart_b, *offsets_b, *owner_b, *cnt_b;
+  int2* perm1_b;
   int64_t total;
 };
+
+// view with the per-batch buffers of `set` in the primary slots
+static inline hsk_ws hsk_select(const hsk_ws& w, int set) {
+  if (set == 0) return w;
+  hsk_ws r = w;
+  std::swap(r.u32, r.u32_b);
+  std::swap(r.it32, r.it32_b);
+  std::swap(r.perm1, r.perm1_b);
+  std::swap(r.perm, r.perm_b);
+  std::swap(r.hist, r.hist_b);
+  std::swap(r.btot, r.btot_b);
+  std::swap(r.bstart, r.bstart_b);
+  std::swap(r.offsets, r.offsets_b);
+  std::swap(r.owner, r.owner_b);
+  std::swap(r.cnt, r.cnt_b);
+  return r;
+}
 
 static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
                         int64_t max_cols) {
@@ -69,6 +90,16 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.dUb = (float*)take(max_batch * dim * 4);
   w.loss_b = (double*)take(max_batch * 8);
   w.adam_tab = (float2*)take((HSK_ADAM_TAB_LEN + 1) * sizeof(float2));
+  w.u32_b = (int*)take(max_batch * 4);
+  w.it32_b = (int*)take(ent * 4);
+  w.perm1_b = (int2*)take(ent * 8);
+  w.perm_b = (int*)take(ent * 4);
+  w.hist_b = (int*)take((hist_elems > 0 ? hist_elems : 4) * 4);
+  w.btot_b = (int*)take(HSK_SORT_MAX_BUCKETS * 4);
+  w.bstart_b = (int*)take((HSK_SORT_MAX_BUCKETS + 1) * 4);
+  w.offsets_b = (int*)take((n_items + 1) * 4);
+  w.owner_b = (int*)take(n_users * 4);
+  w.cnt_b = (int*)take(n_users * 4);
   w.total = off;
   return w;
 }
@@ -129,7 +160,9 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   hipStream_t stream = (hipStream_t)stream_;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   HSK_HIP(hipMemsetAsync(w.cnt, 0, st->n_users * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.cnt_b, 0, st->n_users * 4, stream));
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner, st->n_users, HSK_OWNER_NONE);
+  k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner_b, st->n_users, HSK_OWNER_NONE);
   HSK_LAUNCH_CHECK();
   // rows are current up to the steps already applied (0 for a fresh optimiser)
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.last_step, st->n_users, (int)st->step);
@@ -219,20 +252,32 @@ static inline void hsk_stage_mark(const hsk_bprmf_state* st, int stage, bool beg
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// aux handle: a side stream + events so that independent stages of one step overlap
+// aux handle: side stream on which the NEXT batch is sampled and sorted while the current one trains
 // ---------------------------------------------------------------------------------------------
+// prep + item sort (5 short, latency-bound kernels, ~48 us at the ml10m shape) depend on nothing a step writes
+// except the owner map they build themselves.  With an aux handle and a hint naming the next batch
+// (hsk_bprmf_hint_next) they run on the side stream, into the other set of per-batch buffers, forked after the
+// forward kernel (which occupies every wave slot of the chip on its own) so that they overlap the item and user
+// passes.  The next call joins on one event.  Results are identical to the inline order: same RNG stream id,
+// same sort.
 struct hsk_aux {
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_fwd = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_ready = nullptr;
+  bool hint_valid = false;
+  const int64_t* hint_order = nullptr;
+  int64_t hint_start = 0, hint_batch = 0, hint_nneg = 0;
+  bool pf_valid = false;  // a prefetched batch sits in set `cur_set ^ 1`
+  const int64_t* pf_order = nullptr;
+  int64_t pf_start = 0, pf_batch = 0, pf_nneg = 0, pf_step = 0;
+  int cur_set = 0;  // buffers of the batch of the latest step
 };
 
 extern "C" void hsk_aux_destroy(void* a_) {
   hsk_aux* a = (hsk_aux*)a_;
   if (!a) return;
+  if (a->side) (void)hipStreamSynchronize(a->side);
   if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
-  if (a->ev_sorted) (void)hipEventDestroy(a->ev_sorted);
-  if (a->ev_fwd) (void)hipEventDestroy(a->ev_fwd);
-  if (a->ev_join) (void)hipEventDestroy(a->ev_join);
+  if (a->ev_ready) (void)hipEventDestroy(a->ev_ready);
   if (a->side) (void)hipStreamDestroy(a->side);
   delete a;
 }
@@ -241,15 +286,34 @@ extern "C" void* hsk_aux_create(void) {
   hsk_aux* a = new hsk_aux();
   bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&a->ev_sorted, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&a->ev_fwd, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     hsk_set_error("hsk_aux_create: could not create the side stream / events");
     hsk_aux_destroy(a);
     return nullptr;
   }
   return a;
+}
+
+extern "C" int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
+                                   int64_t n_neg) {
+  HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
+  hsk_aux* a = (hsk_aux*)st->aux;
+  HSK_REQUIRE(a != nullptr, HSK_ERR_INVALID, "hint_next needs an aux handle in the state");
+  if (batch <= 0) {
+    a->hint_valid = false;
+    return HSK_OK;
+  }
+  HSK_REQUIRE(batch <= st->max_batch && n_neg >= 1 && n_neg + 1 <= st->max_cols, HSK_ERR_INVALID,
+              "hint: batch %lld / n_neg %lld outside the workspace limits", (long long)batch, (long long)n_neg);
+  HSK_REQUIRE(start >= 0 && start + batch <= st->nnz, HSK_ERR_INVALID, "hint: range [%lld, %lld) outside nnz %lld",
+              (long long)start, (long long)(start + batch), (long long)st->nnz);
+  a->hint_valid = true;
+  a->hint_order = order;
+  a->hint_start = start;
+  a->hint_batch = batch;
+  a->hint_nneg = n_neg;
+  return HSK_OK;
 }
 
 // =============================================================================================
@@ -267,8 +331,6 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
     k_user_flush<1><<<(unsigned)U, 256, 0, stream>>>(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias,
                                                      st->m_user_bias, st->v_user_bias, w.last_step, U, D, (int)st->step,
                                                      c, w.adam_tab, HSK_ADAM_TAB_LEN);
-  int rc = 0;
-  if (rc) return rc;
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
@@ -308,43 +370,105 @@ static inline double hsk_loss_norm(int kind, double batch, double n_cols) {
   return 1.0 / (batch * (n_cols - 1.0));
 }
 
-// stages after prep filled u32 / it32 / owner / cnt
-static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t K, hipStream_t stream) {
-  const int64_t total = B * K;
-  const int I = (int)st->n_items, U = (int)st->n_users, D = (int)st->dim;
-  st->step += 1;
-  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
-  const double inv_bn_d = hsk_loss_norm(st->loss_kind, (double)B, (double)K);
-  const float inv_bn = (float)inv_bn_d;
+// device batch construction: positives order[start .. start+batch) + sampled negatives, owner map
+static int hsk_launch_prep_sample(const hsk_bprmf_state* st, const hsk_ws& w, const int64_t* order, int64_t start,
+                                  int64_t batch, int64_t n_neg, uint64_t stream_id, hipStream_t stream) {
+  HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
+                                st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
+                                st->csr_indices, (int)st->n_items, st->seed, stream_id, w.u32, w.it32, w.owner, w.cnt,
+                                st->status, 0, hsk_alias{st->alias_prob, st->alias_idx}));
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
 
+// item sort of the entries in w.it32 -> w.perm / w.offsets
+static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t total, hipStream_t stream) {
+  const int I = (int)st->n_items;
   hsk_sort_plan plan;
   HSK_REQUIRE(hsk_make_sort_plan(I, total, &plan) == 0, HSK_ERR_UNSUPPORTED, "item sort: n_items too large");
   const size_t bucket_lds = (size_t)5 * plan.ipb * sizeof(int);
   if (bucket_lds > 65536)
     HSK_HIP(hipFuncSetAttribute((const void*)k_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds));
-  // The item sort only depends on prep and is only needed by k_item_update: with an aux handle it runs on the
-  // side stream, concurrently with the catch-up and the forward kernel (fork/join by events, capturable).
+  HSK_STAGE(HSK_STAGE_SCAN, {
+    k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist);
+    k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
+  });
+  HSK_LAUNCH_CHECK();
+  HSK_STAGE(HSK_STAGE_SCATTER, {
+    k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist, w.btot,
+                                                                                 w.perm1, w.bstart);
+    k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(w.perm1, (int)total, I, plan, w.bstart, w.perm,
+                                                                         w.offsets);
+  });
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+// a prefetched batch that the next call does not consume: give its owner map back
+static int hsk_discard_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, hipStream_t stream) {
+  hsk_aux* a = (hsk_aux*)st->aux;
+  if (!a || !a->pf_valid) return HSK_OK;
+  const hsk_ws w = hsk_select(w_all, a->cur_set ^ 1);
+  HSK_HIP(hipStreamWaitEvent(stream, a->ev_ready, 0));
+  k_release_owner<<<(unsigned)hsk_ceil_div(a->pf_batch, 256), 256, 0, stream>>>(w.u32, (int)a->pf_batch, w.owner, w.cnt);
+  HSK_LAUNCH_CHECK();
+  a->pf_valid = false;
+  return HSK_OK;
+}
+
+// the next batch, if the caller named it: sampled and sorted on the side stream from here on
+// Fork point.  A forward kernel of >= 512 workgroups occupies most wave slots of the chip for its whole duration:
+// side-stream kernels forked before it only get in as it drains, and delay its workgroups (measured at B=4096,
+// D=512: 243 us/step forked before, 231 us forked after, 252 us without prefetch).  A small forward kernel leaves
+// the chip mostly idle and the step is launch-latency-bound: fork as early as possible (B=128: 65 us before, 97 us
+// after, 83 us without).
+static bool hsk_pf_early(int64_t B) { return B < 2048; }
+#define HSK_PREFETCH_MIN_ENTRIES 4096
+
+static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set, hipStream_t stream) {
   hsk_aux* aux = (hsk_aux*)st->aux;
-  hipStream_t main_stream = stream;
-  if (aux) {
-    HSK_HIP(hipEventRecord(aux->ev_fork, main_stream));
-    HSK_HIP(hipStreamWaitEvent(aux->side, aux->ev_fork, 0));
+  if (!aux || !aux->hint_valid) return HSK_OK;
+  if (aux->hint_batch * (aux->hint_nneg + 1) < HSK_PREFETCH_MIN_ENTRIES) {
+    aux->hint_valid = false;  // a few hundred entries: the fork/join events cost more than the five tiny kernels
+    return HSK_OK;
   }
-  {
-    hipStream_t stream = aux ? aux->side : main_stream;
-    HSK_STAGE(HSK_STAGE_SCAN, {
-      k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist);
-      k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
-    });
-    HSK_LAUNCH_CHECK();
-    HSK_STAGE(HSK_STAGE_SCATTER, {
-      k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist,
-                                                                                   w.btot, w.perm1, w.bstart);
-      k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(w.perm1, (int)total, I, plan, w.bstart,
-                                                                           w.perm, w.offsets);
-    });
-    HSK_LAUNCH_CHECK();
-    if (aux) HSK_HIP(hipEventRecord(aux->ev_sorted, stream));
+  const hsk_ws wn = hsk_select(w_all, set ^ 1);
+  HSK_HIP(hipEventRecord(aux->ev_fork, stream));
+  HSK_HIP(hipStreamWaitEvent(aux->side, aux->ev_fork, 0));
+  int prc = hsk_launch_prep_sample(st, wn, aux->hint_order, aux->hint_start, aux->hint_batch, aux->hint_nneg,
+                                   (uint64_t)st->step, aux->side);
+  if (!prc) prc = hsk_launch_sort(st, wn, aux->hint_batch * (aux->hint_nneg + 1), aux->side);
+  if (prc) return prc;
+  HSK_HIP(hipEventRecord(aux->ev_ready, aux->side));
+  aux->pf_valid = true;
+  aux->pf_order = aux->hint_order;
+  aux->pf_start = aux->hint_start;
+  aux->pf_batch = aux->hint_batch;
+  aux->pf_nneg = aux->hint_nneg;
+  aux->pf_step = st->step;
+  aux->hint_valid = false;
+  return HSK_OK;
+}
+
+// stages after prep filled u32 / it32 / owner / cnt of `w` (and, with sorted == true, the item sort too)
+static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool sorted, int64_t B, int64_t K,
+                        hipStream_t stream) {
+  const hsk_ws w = hsk_select(w_all, set);
+  const int64_t total = B * K;
+  const int U = (int)st->n_users, D = (int)st->dim;
+  st->step += 1;
+  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
+  const double inv_bn_d = hsk_loss_norm(st->loss_kind, (double)B, (double)K);
+  const float inv_bn = (float)inv_bn_d;
+  hsk_aux* aux = (hsk_aux*)st->aux;
+  if (aux) aux->cur_set = set;
+  if (!sorted) {
+    int src = hsk_launch_sort(st, w, total, stream);
+    if (src) return src;
+  }
+  if (hsk_pf_early(B)) {
+    int prc = hsk_launch_prefetch(st, w_all, set, stream);
+    if (prc) return prc;
   }
 
   int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
@@ -378,12 +502,21 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
       HSK_LAUNCH_FWD(HSK_LOSS_BPR);
     }
 #undef HSK_LAUNCH_FWD
-    if (aux) {
-      // side stream: loss reduction + global bias as soon as the forward is done; main: join the sort
-      (void)hipEventRecord(aux->ev_fwd, stream);
-      (void)hipStreamWaitEvent(aux->side, aux->ev_fwd, 0);
-      (void)hipStreamWaitEvent(stream, aux->ev_sorted, 0);
-    }
+    return HSK_OK;
+  });
+  if (rc) return rc;
+  HSK_LAUNCH_CHECK();
+
+  if (!hsk_pf_early(B)) {
+    int prc = hsk_launch_prefetch(st, w_all, set, stream);
+    if (prc) return prc;
+  }
+
+  rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
+    constexpr int V = decltype(v_)::value;
+    constexpr int NCH = decltype(n_)::value;
+    constexpr bool FULL = decltype(f_)::value;
+    constexpr int R = (V * NCH >= 16) ? 2 : 4;
     HSK_STAGE(HSK_STAGE_ITEM, hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, st->user_emb, w.u32, (int)K, c, nullptr,
                                                                           nullptr, stream));
     if (st->lazy_users) {
@@ -404,18 +537,10 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w, int64_t B, int64_t
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
   if (!st->lazy_users) {
-    hipStream_t stream = aux ? aux->side : main_stream;
     HSK_STAGE(HSK_STAGE_FINISH, k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out,
                                                                        st->global_bias, st->m_global_bias,
                                                                        st->v_global_bias, c));
     HSK_LAUNCH_CHECK();
-    if (aux) {
-      HSK_HIP(hipEventRecord(aux->ev_join, stream));
-      HSK_HIP(hipStreamWaitEvent(main_stream, aux->ev_join, 0));
-    }
-  } else if (aux) {
-    HSK_HIP(hipEventRecord(aux->ev_join, aux->side));
-    HSK_HIP(hipStreamWaitEvent(main_stream, aux->ev_join, 0));
   }
   if (st->lazy_users && (st->step % HSK_FLUSH_EVERY) == 0) {
     int frc = 0;
@@ -443,11 +568,14 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   const int64_t total = batch * n_cols;
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
+  if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
+  const int set = st->aux ? (((hsk_aux*)st->aux)->cur_set ^ 1) : 0;
+  const hsk_ws ws = hsk_select(w, set);
   HSK_STAGE(HSK_STAGE_PREP, k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
-                                u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, w.u32,
-                                w.it32, w.owner, w.cnt, st->status));
+                                u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, ws.u32,
+                                ws.it32, ws.owner, ws.cnt, st->status));
   HSK_LAUNCH_CHECK();
-  return hsk_run_step(st, w, batch, n_cols, stream);
+  return hsk_run_step(st, w, set, false, batch, n_cols, stream);
 }
 
 extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
@@ -463,12 +591,19 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   // the RNG stream id is the index of the step about to be taken: every step draws fresh negatives
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
-  HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
-                                st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
-                                st->csr_indices, (int)st->n_items, st->seed, (uint64_t)st->step, w.u32, w.it32,
-                                w.owner, w.cnt, st->status, 0, hsk_alias{st->alias_prob, st->alias_idx}));
-  HSK_LAUNCH_CHECK();
-  return hsk_run_step(st, w, batch, n_neg + 1, stream);
+  hsk_aux* aux = (hsk_aux*)st->aux;
+  if (aux && aux->pf_valid && aux->pf_order == order && aux->pf_start == start && aux->pf_batch == batch &&
+      aux->pf_nneg == n_neg && aux->pf_step == st->step) {
+    // this batch was sampled and sorted on the side stream during the previous step
+    aux->pf_valid = false;
+    HSK_HIP(hipStreamWaitEvent(stream, aux->ev_ready, 0));
+    return hsk_run_step(st, w, aux->cur_set ^ 1, true, batch, n_neg + 1, stream);
+  }
+  if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
+  const int set = aux ? (aux->cur_set ^ 1) : 0;
+  if ((rc = hsk_launch_prep_sample(st, hsk_select(w, set), order, start, batch, n_neg, (uint64_t)st->step, stream)))
+    return rc;
+  return hsk_run_step(st, w, set, false, batch, n_neg + 1, stream);
 }
 
 extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
@@ -487,6 +622,7 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   if ((rc = hsk_check_batch(st, batch, n_cols))) return rc;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   const int64_t total = batch * n_cols;
+  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set);
   k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
                                                                                       u_out, i_out);
   HSK_LAUNCH_CHECK();

@@ -561,3 +561,13 @@ __global__ __launch_bounds__(256) void k_widen_batch(const int* __restrict__ u32
   if (e < total) i_out[e] = it32[e];
   if (e < B) u_out[e] = u32[e];
 }
+
+// undo the owner-map contribution of a batch that will not be trained on (a discarded prefetch)
+__global__ __launch_bounds__(256) void k_release_owner(const int* __restrict__ u32, int B, int* __restrict__ owner,
+                                                       int* __restrict__ cnt) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int u = u32[b];
+  owner[u] = HSK_OWNER_NONE;
+  cnt[u] = 0;
+}

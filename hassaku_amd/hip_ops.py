@@ -216,7 +216,7 @@ class BprMfFusedState:
 
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, seed=0,
-                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=False,
+                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=True,
                  loss='bpr', log_adjust=0.0, alias=None):
         _lib.require_gpu()
         self.lib = _lib.load()
@@ -280,10 +280,10 @@ class BprMfFusedState:
         st.timing_every = 1
         st.timing_now = 0
         self._timing = None
-        # optional side stream for the item sort / loss reduction.  Measured on MI355X (profiles/README.md): the
-        # forward kernel fills every wave slot, the side kernels only run in its shadow and the cross-stream
-        # event waits cost ~6 us each -> no gain, so it is off by default.
+        # optional side stream: the batch named by hint_next() is sampled and item-sorted there while the current
+        # step's item / user passes run (cross-step prefetch; results identical to the un-hinted sequence)
         self._aux = self.lib.hsk_aux_create() if overlap else None
+        self._hint_order = None
         st.aux = self._aux
         st.loss_out, st.status = _p(self.loss_out), _p(self.status)
         self.st = st
@@ -311,6 +311,19 @@ class BprMfFusedState:
                 raise ValueError('order too short')
         _lib.check(self.lib.hsk_bprmf_train_step_sampled(ctypes.byref(self.st), _p(order), start, batch, n_neg,
                                                          _stream()), 'hsk_bprmf_train_step_sampled')
+
+    def hint_next(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int):
+        """Name the batch of the NEXT step_sampled call so that the step issued now prepares it on the side stream.
+        No-op without overlap=True.  batch <= 0 clears a pending hint."""
+        if self._aux is None:
+            return
+        if order is not None and batch > 0:
+            _chk(order, torch.int64, 'order')
+            if start + batch > order.numel():
+                raise ValueError('order too short')
+        self._hint_order = order                      # keep the tensor alive until the hinted step was issued
+        _lib.check(self.lib.hsk_bprmf_hint_next(ctypes.byref(self.st), _p(order), start, batch, n_neg),
+                   'hsk_bprmf_hint_next')
 
     def last_batch(self, batch: int, n_cols: int):
         u = torch.empty(batch, dtype=torch.int64, device=self.device)

@@ -168,7 +168,12 @@ class Trainer:
         loader, fused = self.train_loader, self.fused
         if isinstance(loader, TrainDataLoader):
             n_neg = loader.interaction_sampler.n_neg
-            for order, start, nb in loader.fused_batches():
+            # the loader knows its next batch: each step samples + sorts it on the side stream (device-side
+            # counterpart of the reference's DataLoader prefetch, train/trainer.py:127-130)
+            batches = list(loader.fused_batches())
+            for k, (order, start, nb) in enumerate(batches):
+                if k + 1 < len(batches):
+                    fused.hint_next(*batches[k + 1], n_neg)
                 fused.step_sampled(order, start, nb, n_neg)
         else:
             for u_idxs, i_idxs, _labels in loader:

@@ -172,8 +172,8 @@ typedef struct hsk_bprmf_state {
   int32_t timing_mask;
   /* opaque handle from hsk_timing_create, or NULL (no timing) */
   void* timing;
-  /* opaque handle from hsk_aux_create, or NULL: side stream on which the item sort and the loss reduction of a
-     step run concurrently with the forward kernel (forked from / joined back into `stream` with events) */
+  /* opaque handle from hsk_aux_create, or NULL: side stream on which the batch named by hsk_bprmf_hint_next is
+     sampled and item-sorted while the current step's item / user passes run (fork / join by events) */
   void* aux;
   /* event-time only every timing_every-th step (<= 1: every step); timing_now is library scratch */
   int32_t timing_every;
@@ -228,10 +228,20 @@ void* hsk_timing_create(void);
 void hsk_timing_destroy(void* timing);
 int hsk_timing_collect(void* timing, double* ms_sum, int64_t* count);
 
-/* Side stream + events for intra-step overlap (host-side objects; create once per state, destroy after the
+/* Side stream + events for cross-step overlap (host-side objects; create once per state, destroy after the
  * last step has completed).  Returns NULL on failure. */
 void* hsk_aux_create(void);
 void hsk_aux_destroy(void* aux);
+
+/* Name the batch the NEXT hsk_bprmf_train_step_sampled call will ask for (same order pointer, start, batch,
+ * n_neg).  The step issued after the hint samples and sorts that batch on the aux side stream, behind its own
+ * forward kernel, into a second set of workspace buffers; the next call finds it ready.  Purely a scheduling hint:
+ * the batch, its negatives (RNG stream id = the step index it is consumed at) and every result are identical to
+ * the un-hinted sequence, and a hint that turns out wrong is discarded.  The data loader's epoch loop
+ * (data/dataloader.py:92-129 feeding train/trainer.py:127-160 in the reference) knows its next batch, which is what
+ * makes this the device-side counterpart of DataLoader prefetching.  batch <= 0 clears a pending hint.
+ * Needs st->aux; `order` must stay valid and unchanged until the hinted step has been issued. */
+int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch, int64_t n_neg);
 
 /* Bring lazily-updated user rows up to st->step (no-op when lazy_users == 0). */
 int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);

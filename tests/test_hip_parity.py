@@ -301,6 +301,69 @@ def test_sampler_user_with_all_items_gives_up(ops):
         ops.raise_on_status(status)
 
 
+def _run_sampled_epoch(ops, overlap, hints, steps=70):
+    """`steps` device-sampled steps over a fixed interaction order; hints: None | 'right' | 'mixed'."""
+    rng = np.random.RandomState(4)
+    n_users, n_items, D, B, N = 150, 260, 96, 64, 70     # 64 x 71 entries: above the prefetch minimum (4096)
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.15)
+    pairs = pairs[rng.permutation(len(pairs))]
+    assert len(pairs) >= steps * B
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
+    st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, overlap=overlap, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                         coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+    order = torch.from_numpy(np.random.RandomState(6).permutation(len(pairs))).cuda()
+    batches, losses = [], []
+    for s in range(steps):
+        nb = B if s % 7 != 6 else 40                      # ragged batches in between
+        if hints and s + 1 < steps:
+            nb_next = B if (s + 1) % 7 != 6 else 40
+            if hints == 'right' or s % 3 != 1:
+                st.hint_next(order, (s + 1) * B, nb_next, N)
+            else:
+                st.hint_next(order, (s + 5) % steps * B, nb_next, N)   # a wrong guess: must be discarded cleanly
+        if hints == 'mixed' and s % 11 == 5:
+            u0, i0 = st.last_batch(len(batches[-1][0]), N + 1)   # exactly the rows the previous step wrote
+            st.step(u0, i0)                                # an external batch in between also discards the prefetch
+            st.hint_next(order, 0, 0, N)
+        st.step_sampled(order, s * B, nb, N)
+        u, i = st.last_batch(nb, N + 1)
+        batches.append((u.cpu().numpy(), i.cpu().numpy()))
+        losses.append(st.last_loss())
+    st.flush()
+    st.check_status()
+    out = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    out.update({'m.' + k: v.cpu().numpy().copy() for k, v in st.m.items() if v is not None})
+    return out, batches, losses
+
+
+def test_prefetched_batches_change_nothing(ops):
+    """hsk_bprmf_hint_next: batches sampled + sorted one step ahead on the side stream give the same batches, losses
+    and parameters, bit for bit, as the inline sequence -- also across the flush boundary (step 64)."""
+    base, b0, l0 = _run_sampled_epoch(ops, overlap=False, hints=None)
+    pref, b1, l1 = _run_sampled_epoch(ops, overlap=True, hints='right')
+    assert l0 == l1
+    for (u0, i0), (u1, i1) in zip(b0, b1):
+        assert np.array_equal(u0, u1) and np.array_equal(i0, i1)
+    for k in base:
+        assert np.array_equal(base[k], pref[k]), k
+
+
+def test_wrong_hints_are_discarded(ops):
+    """A hint that does not match the next call (or is followed by an external batch) costs time, never results."""
+    base, b0, l0 = _run_sampled_epoch(ops, overlap=True, hints=None)
+    mixed_ref, _, _ = _run_sampled_epoch(ops, overlap=False, hints='mixed')     # hints are no-ops without overlap
+    mixed, _, _ = _run_sampled_epoch(ops, overlap=True, hints='mixed')
+    for k in mixed:
+        assert np.array_equal(mixed[k], mixed_ref[k]), k
+    plain, b1, l1 = _run_sampled_epoch(ops, overlap=False, hints=None)
+    assert l0 == l1
+    for k in base:
+        assert np.array_equal(base[k], plain[k]), k
+
+
 def test_fused_sampled_step_matches_oracle_on_its_own_batch(ops, oracle):
     """Device-built batch: read back (u, i) the step used, check sampler invariants, replay in the oracle."""
     rng = np.random.RandomState(3)
