@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of tools_profile.sh into profiles/<name>/{kernel_stats.csv, pmc_summary.json}.
+usage: tools_pmc_summary.py gpurun_out/prof_<tag> profiles/<name>
+Only this repo's kernels (k_*) are kept; counter values are the per-dispatch means, in the units rocprofv3 reports."""
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    return name.split('(')[0].replace('void ', '').strip()
+
+
+summary = {}
+for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+    for path in glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(path)):
+            if r['Counter_Name'] != counter:
+                continue
+            k = short(r['Kernel_Name'])
+            if not k.startswith('k_'):
+                continue
+            a = acc.setdefault(k, [0.0, 0])
+            a[0] += float(r['Counter_Value'])
+            a[1] += 1
+        for k, (tot, n) in acc.items():
+            row = summary.setdefault(k, {})
+            row[counter + '_KB_mean'] = tot / n
+            row['dispatches'] = n
+json.dump(summary, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
+
+for path in glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True):
+    rows = list(csv.DictReader(open(path)))
+    with open(os.path.join(dst, 'kernel_stats.csv'), 'w', newline='') as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in rows:
+            r['Name'] = short(r['Name'])[:80]
+            w.writerow(r)
+print(json.dumps({k: v for k, v in summary.items() if k.startswith(('k_fwd', 'k_item'))}, indent=1))
