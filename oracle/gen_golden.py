@@ -16,6 +16,10 @@ Fixtures (data only: inputs and the reference's outputs):
   g4_fit.npz          reference Trainer.fit for 2 epochs with the reference loader (seed 64, 0 workers):
                       the batch stream, per-epoch losses, final parameters, validation metrics
   g5_metrics.npz      precision/recall/ndcg_at_k_batch on random logits/labels
+  g7_checkpoint/      a checkpoint directory as the reference leaves it on disk: model.pth written by
+                      save_model_to_path, conf.yml written by save_yaml after parse_conf, and expected.npz =
+                      the saved tensors + the reference model's logits on a fixed (u, i) batch after
+                      load_model_from_path into a fresh instance
 """
 import os
 import sys
@@ -316,6 +320,39 @@ def gen_g5():
     print('g5 ok')
 
 
+def gen_g7():
+    from algorithms.algorithms_utils import AlgorithmsEnum
+    from algorithms.sgd_alg import SGDMatrixFactorization
+    from conf.conf_parser import parse_conf, save_yaml
+    from data.data_utils import DatasetsEnum
+    from utilities.utils import reproducible
+    out = os.path.join(OUT, 'g7_checkpoint')
+    os.makedirs(out, exist_ok=True)
+    reproducible(7)
+    conf = {'embedding_dim': 24, 'use_user_bias': True, 'use_item_bias': True, 'use_global_bias': True,
+            'rec_loss': 'bpr', 'lr': 3e-4, 'wd': 4e-5, 'optimizer': 'adamw', 'neg_train': 10, 'train_batch_size': 32,
+            'data_path': 'unused', 'running_settings': {'use_wandb': False}}
+    conf = parse_conf(conf, AlgorithmsEnum.mf, DatasetsEnum.ml1m)
+    conf['model_path'] = 'g7_checkpoint'            # the reference stores an absolute run directory here
+    conf['dataset_path'] = 'unused'
+    ds = types.SimpleNamespace(n_users=37, n_items=53)
+    model = SGDMatrixFactorization.build_from_conf(conf, ds)
+    with torch.no_grad():                            # trained-looking values everywhere, biases included
+        for p in model.parameters():
+            p.add_(torch.randn_like(p) * 0.3)
+    model.save_model_to_path(out)
+    save_yaml(out, conf)
+    fresh = SGDMatrixFactorization.build_from_conf(conf, ds)
+    fresh.load_model_from_path(out)
+    g = torch.Generator().manual_seed(3)
+    u = torch.randint(0, 37, (19,), generator=g)
+    i = torch.randint(0, 53, (19, 8), generator=g)
+    fx = {'u_idx': u.numpy(), 'i_idx': i.numpy(), 'logits': fresh.predict(u, i).numpy()}
+    fx.update({'sd.' + k: v for k, v in state_np(fresh).items()})
+    np.savez_compressed(os.path.join(out, 'expected.npz'), **fx)
+    print('g7 ok', sorted(k for k in fx if k.startswith('sd.')))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     import_reference()
@@ -325,3 +362,4 @@ if __name__ == '__main__':
     gen_g4()
     gen_g5()
     gen_g6()
+    gen_g7()
