@@ -35,7 +35,7 @@ class HskBprmfState(ctypes.Structure):
         ('lazy_users', c_int32), ('timing_mask', c_int32),
         ('timing', c_void_p), ('aux', c_void_p),
         ('timing_every', c_int32), ('timing_now', c_int32),
-        ('loss_kind', c_int32), ('reserved1', c_int32), ('ssm_log_adjust', c_double),
+        ('loss_kind', c_int32), ('opt_kind', c_int32), ('ssm_log_adjust', c_double),
         ('alias_prob', c_void_p), ('alias_idx', c_void_p),
         ('loss_out', c_void_p), ('status', c_void_p),
     ]
@@ -68,6 +68,7 @@ SIGNATURES = {
     'hsk_mf_backward': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                 c_int64, c_void_p] + [c_void_p] * 5 + [c_void_p, c_void_p]),
     'hsk_adamw_dense': (c_int, [c_void_p] * 4 + [c_int64] + [c_double] * 5 + [c_int64, c_void_p]),
+    'hsk_opt_dense': (c_int, [c_int] + [c_void_p] * 4 + [c_int64] + [c_double] * 5 + [c_int64, c_void_p]),
     'hsk_sample_negatives_uniform': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                              c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     'hsk_sample_negatives_alias': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,

@@ -130,9 +130,17 @@ __host__ __device__ __forceinline__ hsk_u32x4 hsk_philox4x32_10(hsk_u32x4 ctr, u
   return ctr;
 }
 
-// ---- AdamW scalars (host-computed exactly like torch.optim.adamw's single-tensor path) ---------
+// ---- optimiser scalars (host-computed exactly like torch.optim's single-tensor paths) ---------
+// One struct serves the three optimisers train/trainer.py:48-53 of the reference selects by conf['optimizer']:
+//   adamw    decoupled decay   p *= 1 - lr*wd;          then Adam on g
+//   adam     L2 decay          g += wd * p;             then Adam on g           (decay = 1)
+//   adagrad  L2 decay          g += wd * p;  v += g*g;  p -= lr * g / (sqrt(v) + eps)   (lr_decay = 0; m unused)
+#define HSK_OPT_KIND_ADAM_FAMILY 0
+#define HSK_OPT_KIND_ADAGRAD 1
 struct hsk_adamw_consts {
-  float decay;      // 1 - lr*wd
+  float decay;      // 1 - lr*wd (adamw) or 1
+  float l2;         // wd (adam, adagrad) or 0
+  int kind;         // HSK_OPT_KIND_*
   float w1;         // 1 - beta1   (lerp weight)
   float beta2;      // beta2
   float one_m_b2;   // 1 - beta2
@@ -152,8 +160,23 @@ struct hsk_adamw_consts {
 #define HSK_ADAM_IEEE 0
 #endif
 
+// GEN = false: compile-time AdamW (no L2 term, no optimiser branch) for the kernels whose time is this function
+// (the zero-gradient replay is VALU-bound: the generic form costs it +20 %); GEN = true serves all three optimisers.
+template <bool GEN = true>
 __device__ __forceinline__ void hsk_adamw_update(float& p, float& m, float& v, float g,
                                                  const hsk_adamw_consts& c) {
+  if (GEN) {
+    g = fmaf(c.l2, p, g);   // grad.add(param, alpha=weight_decay); exact no-op when l2 == 0
+    if (c.kind == HSK_OPT_KIND_ADAGRAD) {   // uniform branch
+      v = fmaf(g, g, v);    // state_sum.addcmul_(grad, grad)
+#if HSK_ADAM_IEEE
+      p = p - c.step_size * (g / (sqrtf(v) + c.eps));
+#else
+      p = fmaf(-c.step_size * g, __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + c.eps), p);
+#endif
+      return;
+    }
+  }
   p = p * c.decay;
   m = fmaf(c.w1, g - m, m);
   v = fmaf(c.one_m_b2 * g, g, v * c.beta2);
@@ -170,12 +193,28 @@ __device__ __forceinline__ void hsk_adamw_update(float& p, float& m, float& v, f
 
 #ifdef __cplusplus
 #include <cmath>
+// opt: HSK_OPT_ADAMW / HSK_OPT_ADAM / HSK_OPT_ADAGRAD of hassaku_hip.h (0 / 1 / 2)
 static inline hsk_adamw_consts hsk_make_adamw_consts(double lr, double b1, double b2, double eps,
-                                                     double wd, int64_t step) {
+                                                     double wd, int64_t step, int opt = 0) {
   hsk_adamw_consts c;
+  if (opt == 2) {  // adagrad: clr = lr / (1 + (step-1)*lr_decay) with lr_decay = 0
+    c.decay = 1.f;
+    c.l2 = (float)wd;
+    c.kind = HSK_OPT_KIND_ADAGRAD;
+    c.w1 = 0.f;
+    c.beta2 = 1.f;
+    c.one_m_b2 = 0.f;
+    c.step_size = (float)lr;
+    c.bc2_sqrt = 1.f;
+    c.rbc2_sqrt = 1.f;
+    c.eps = (float)eps;
+    return c;
+  }
   double bc1 = 1.0 - std::pow(b1, (double)step);
   double bc2 = 1.0 - std::pow(b2, (double)step);
-  c.decay = (float)(1.0 - lr * wd);
+  c.kind = HSK_OPT_KIND_ADAM_FAMILY;
+  c.l2 = (opt == 1) ? (float)wd : 0.f;
+  c.decay = (opt == 1) ? 1.f : (float)(1.0 - lr * wd);
   c.w1 = (float)(1.0 - b1);
   c.beta2 = (float)b2;
   c.one_m_b2 = (float)(1.0 - b2);

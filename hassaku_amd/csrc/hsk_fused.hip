@@ -113,7 +113,7 @@ extern "C" int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, i
 
 // lazy replay needs the per-step scalars to be constant beyond the table
 static bool hsk_adam_tab_saturates(const hsk_bprmf_state* st) {
-  const hsk_adamw_consts a = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, HSK_ADAM_TAB_LEN);
+  const hsk_adamw_consts a = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, HSK_ADAM_TAB_LEN, st->opt_kind);
   const hsk_adamw_consts b = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, (int64_t)1 << 40);
   return a.step_size == b.step_size && a.bc2_sqrt == b.bc2_sqrt && a.rbc2_sqrt == b.rbc2_sqrt;
 }
@@ -149,6 +149,8 @@ static int hsk_check_state(const hsk_bprmf_state* st) {
   HSK_REQUIRE(st->step >= 0 && st->step < 0x7ffffff0, HSK_ERR_UNSUPPORTED, "step counter out of range");
   HSK_REQUIRE(st->loss_kind >= HSK_LOSS_BPR && st->loss_kind <= HSK_LOSS_SSM, HSK_ERR_INVALID, "unknown loss_kind %d",
               st->loss_kind);
+  HSK_REQUIRE(st->opt_kind >= HSK_OPT_ADAMW && st->opt_kind <= HSK_OPT_ADAGRAD, HSK_ERR_INVALID, "unknown opt_kind %d",
+              st->opt_kind);
   HSK_REQUIRE((st->alias_prob == nullptr) == (st->alias_idx == nullptr), HSK_ERR_INVALID,
               "alias table needs both alias_prob and alias_idx");
   return HSK_OK;
@@ -173,7 +175,7 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   std::vector<float2> tab(HSK_ADAM_TAB_LEN + 1);
   tab[0] = make_float2(0.f, 1.f);
   for (int t = 1; t <= HSK_ADAM_TAB_LEN; ++t) {
-    const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, t);
+    const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, t, st->opt_kind);
 #if HSK_ADAM_IEEE
     tab[t] = make_float2(c.step_size, c.bc2_sqrt);
 #else
@@ -322,15 +324,18 @@ extern "C" int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, in
 static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream) {
   const int U = (int)st->n_users, D = (int)st->dim;
   if (st->step == 0) return HSK_OK;
-  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
-  if (D % 2 == 0)
-    k_user_flush<2><<<(unsigned)U, 256, 0, stream>>>(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias,
-                                                     st->m_user_bias, st->v_user_bias, w.last_step, U, D, (int)st->step,
-                                                     c, w.adam_tab, HSK_ADAM_TAB_LEN);
-  else
-    k_user_flush<1><<<(unsigned)U, 256, 0, stream>>>(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias,
-                                                     st->m_user_bias, st->v_user_bias, w.last_step, U, D, (int)st->step,
-                                                     c, w.adam_tab, HSK_ADAM_TAB_LEN);
+  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step, st->opt_kind);
+#define HSK_FLUSH(VV, GEN)                                                                                       \
+  k_user_flush<VV, GEN><<<(unsigned)U, 256, 0, stream>>>(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, \
+                                                         st->m_user_bias, st->v_user_bias, w.last_step, U, D,         \
+                                                         (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN)
+  const bool gen = st->opt_kind != HSK_OPT_ADAMW;
+  if (D % 2 == 0) {
+    if (gen) HSK_FLUSH(2, true); else HSK_FLUSH(2, false);
+  } else {
+    if (gen) HSK_FLUSH(1, true); else HSK_FLUSH(1, false);
+  }
+#undef HSK_FLUSH
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
@@ -353,14 +358,17 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
   const int n_sl = (int)hsk_ceil_div(D, 64 * vs);
   const int n_slices_pad = (n_sl < 8 && 8 % n_sl == 0) ? n_sl : (int)hsk_align_up(n_sl, 8);
   const unsigned groups = (unsigned)hsk_align_up(hsk_ceil_div(I, 4), 8);
-  if (vs == 4)
-    k_item_update_sliced<APPLY, 4><<<groups * n_slices_pad, 256, 0, stream>>>(
-        Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,
-        urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, 1, c, gI_out, gIb_out);
-  else
-    k_item_update_sliced<APPLY, 2><<<groups * n_slices_pad, 256, 0, stream>>>(
-        Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,
-        urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, 1, c, gI_out, gIb_out);
+#define HSK_ITEM_SLICED(VS, GEN)                                                                               \
+  k_item_update_sliced<APPLY, VS, GEN><<<groups * n_slices_pad, 256, 0, stream>>>(                              \
+      Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,     \
+      urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, 1, c, gI_out, gIb_out)
+  const bool gen = APPLY && st->opt_kind != HSK_OPT_ADAMW;   // APPLY == false never calls the update
+  if (vs == 4) {
+    if (gen) HSK_ITEM_SLICED(4, true); else HSK_ITEM_SLICED(4, false);
+  } else {
+    if (gen) HSK_ITEM_SLICED(2, true); else HSK_ITEM_SLICED(2, false);
+  }
+#undef HSK_ITEM_SLICED
 }
 
 // 1 / (number of terms the loss averages over)
@@ -457,10 +465,11 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   const int64_t total = B * K;
   const int U = (int)st->n_users, D = (int)st->dim;
   st->step += 1;
-  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step);
+  const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step, st->opt_kind);
   const double inv_bn_d = hsk_loss_norm(st->loss_kind, (double)B, (double)K);
   const float inv_bn = (float)inv_bn_d;
   hsk_aux* aux = (hsk_aux*)st->aux;
+  const bool gen = st->opt_kind != HSK_OPT_ADAMW;   // generic optimiser arithmetic instead of the AdamW-only kernels
   if (aux) aux->cur_set = set;
   if (!sorted) {
     int src = hsk_launch_sort(st, w, total, stream);
@@ -478,17 +487,17 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
     if (st->lazy_users) {
       // the forward must read current rows: replay the missed zero-gradient steps of this batch's users first
+#define HSK_CATCH_UP(VV, GEN)                                                                                     \
+  HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<VV, GEN><<<(unsigned)B, 256, 0, stream>>>(                            \
+                                st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,      \
+                                st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,         \
+                                w.adam_tab, HSK_ADAM_TAB_LEN)))
       if (D % 2 == 0) {
-        HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<2><<<(unsigned)B, 256, 0, stream>>>(
-                                      st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
-                                      st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,
-                                      w.adam_tab, HSK_ADAM_TAB_LEN)));
+        if (gen) HSK_CATCH_UP(2, true); else HSK_CATCH_UP(2, false);
       } else {
-        HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<1><<<(unsigned)B, 256, 0, stream>>>(
-                                      st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
-                                      st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,
-                                      w.adam_tab, HSK_ADAM_TAB_LEN)));
+        if (gen) HSK_CATCH_UP(1, true); else HSK_CATCH_UP(1, false);
       }
+#undef HSK_CATCH_UP
     }
 #define HSK_LAUNCH_FWD(LK)                                                                                         \
   HSK_STAGE(HSK_STAGE_FWD, (k_fwd_ugrad<V, NCH, FULL, R, LK><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(         \
@@ -523,10 +532,13 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       // + one workgroup for the loss reduction / global bias (no separate finish launch in lazy mode)
       const hsk_finish_args fin = {w.loss_b, (int)B, inv_bn_d, st->loss_out, st->global_bias, st->m_global_bias,
                                    st->v_global_bias};
-      HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>(
-                                    st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
-                                    st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,
-                                    (int)st->step, c, fin)));
+#define HSK_USER_LAZY(GEN)                                                                                          \
+  HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, GEN><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>( \
+                                st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,        \
+                                st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,               \
+                                (int)st->step, c, fin)))
+      if (gen) HSK_USER_LAZY(true); else HSK_USER_LAZY(false);
+#undef HSK_USER_LAZY
     } else {
       HSK_STAGE(HSK_STAGE_USER, (k_user_update<V, NCH, FULL, 0><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
                                     st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,

@@ -10,7 +10,7 @@
 #pragma once
 #include "hsk_rows.h"
 
-template <bool APPLY, int VS>   // VS floats per lane: slice width = 64*VS floats
+template <bool APPLY, int VS, bool GEN>   // VS floats per lane: slice width = 64*VS floats; GEN: see hsk_adamw_update
 __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restrict__ Uw, float* __restrict__ Iw,
                                                             float* __restrict__ Ib, float* __restrict__ mI,
                                                             float* __restrict__ vI, float* __restrict__ mIb,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
     if (APPLY) {
       if (live) {
 #pragma unroll
-        for (int q = 0; q < VS; ++q) hsk_adamw_update(p.v[q], m.v[q], v.v[q], acc.v[q], c);
+        for (int q = 0; q < VS; ++q) hsk_adamw_update<GEN>(p.v[q], m.v[q], v.v[q], acc.v[q], c);
         hsk_stg<VS>(Iw + (long long)i * D + d, p);
         hsk_stg<VS>(mI + (long long)i * D + d, m);
         hsk_stg<VS>(vI + (long long)i * D + d, v);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
         const float gbias = hsk_wave_sum(gb_lane);
         if (lane == 0) {
           float pb = Ib[i], mb = mIb[i], vb = vIb[i];
-          hsk_adamw_update(pb, mb, vb, gbias, c);
+          hsk_adamw_update<GEN>(pb, mb, vb, gbias, c);
           Ib[i] = pb;
           mIb[i] = mb;
           vIb[i] = vb;

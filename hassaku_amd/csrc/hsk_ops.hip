@@ -275,14 +275,15 @@ __global__ __launch_bounds__(256) void k_adamw_dense(float* __restrict__ p, cons
   }
 }
 
-extern "C" int hsk_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
-                               double beta2, double eps, double wd, int64_t step, hsk_stream_t stream_) {
+extern "C" int hsk_opt_dense(int opt_kind, float* p, const float* g, float* m, float* v, int64_t n, double lr,
+                             double beta1, double beta2, double eps, double wd, int64_t step, hsk_stream_t stream_) {
+  HSK_REQUIRE(opt_kind >= HSK_OPT_ADAMW && opt_kind <= HSK_OPT_ADAGRAD, HSK_ERR_INVALID, "unknown opt_kind %d", opt_kind);
   HSK_REQUIRE(p && m && v, HSK_ERR_INVALID, "NULL pointer argument");
   HSK_REQUIRE(n >= 0 && step >= 1, HSK_ERR_INVALID, "need n >= 0 and step >= 1");
   HSK_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0, HSK_ERR_INVALID,
               "buffers must be 16-byte aligned");
   if (n == 0) return HSK_OK;
-  const hsk_adamw_consts c = hsk_make_adamw_consts(lr, beta1, beta2, eps, wd, step);
+  const hsk_adamw_consts c = hsk_make_adamw_consts(lr, beta1, beta2, eps, wd, step, opt_kind);
   const int64_t n4 = n >> 2;
   int64_t blocks = hsk_ceil_div(n4 > 0 ? n4 : 1, 256);
   if (blocks > 2048) blocks = 2048;
@@ -290,6 +291,11 @@ extern "C" int hsk_adamw_dense(float* p, const float* g, float* m, float* v, int
   k_adamw_dense<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(p, g, m, v, (long long)n, c);
   HSK_LAUNCH_CHECK();
   return HSK_OK;
+}
+
+extern "C" int hsk_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                               double beta2, double eps, double wd, int64_t step, hsk_stream_t stream_) {
+  return hsk_opt_dense(HSK_OPT_ADAMW, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, stream_);
 }
 
 // bce / sampled-softmax loss + gradient wrt logits, one wave per row (see hsk_rec_loss_grad in the header)

@@ -349,7 +349,7 @@ __device__ __forceinline__ hsk_adamw_consts hsk_consts_at(const hsk_adamw_consts
 // Zero-gradient replay of one user row by a whole 256-thread workgroup (thread t owns VV consecutive elements per
 // pass): the replay is a serial chain of `to - from` dependent updates per element, so a row is spread over as
 // many lanes as it has elements instead of being held by one wave.
-template <int VV>
+template <int VV, bool GEN>
 __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, float* __restrict__ mrow,
                                                   float* __restrict__ vrow, int D, int from, int to,
                                                   const hsk_adamw_consts& base, const float2* __restrict__ tab,
@@ -359,7 +359,7 @@ __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, floa
     for (int t = from + 1; t <= to; ++t) {
       const hsk_adamw_consts c = hsk_consts_at(base, tab, tab_len, t);
 #pragma unroll
-      for (int q = 0; q < VV; ++q) hsk_adamw_update(p.v[q], m.v[q], v.v[q], 0.f, c);
+      for (int q = 0; q < VV; ++q) hsk_adamw_update<GEN>(p.v[q], m.v[q], v.v[q], 0.f, c);
     }
     hsk_stg<VV>(prow + d0, p);
     hsk_stg<VV>(mrow + d0, m);
@@ -369,7 +369,7 @@ __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, floa
 
 // Lazy mode, before the forward: one workgroup per batch entry; the owner (lowest b) of each distinct user brings
 // that user's row up to step-1, so the gather/score kernels read current parameters.
-template <int VV>
+template <int VV, bool GEN>
 __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, float* __restrict__ mU,
                                                        float* __restrict__ vU, float* __restrict__ Ub,
                                                        float* __restrict__ mUb, float* __restrict__ vUb,
@@ -383,13 +383,13 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
   if (owner[row] != b) return;
   const int done = last_step[row];
   if (done >= step - 1) return;
-  hsk_row_replay_wg<VV>(Uw + (long long)row * D, mU + (long long)row * D, vU + (long long)row * D, D, done, step - 1,
-                        c, tab, tab_len);
+  hsk_row_replay_wg<VV, GEN>(Uw + (long long)row * D, mU + (long long)row * D, vU + (long long)row * D, D, done,
+                             step - 1, c, tab, tab_len);
   __syncthreads();  // every thread has read last_step[row]
   if (threadIdx.x == 0) {
     if (Ub) {
       float pb = Ub[row], mb = mUb[row], vb = vUb[row];
-      for (int t = done + 1; t <= step - 1; ++t) hsk_adamw_update(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
+      for (int t = done + 1; t <= step - 1; ++t) hsk_adamw_update<GEN>(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
       Ub[row] = pb;
       mUb[row] = mb;
       vUb[row] = vb;
@@ -439,7 +439,7 @@ __device__ __forceinline__ void hsk_finish_block(const hsk_finish_args& f, const
 
 // Lazy mode, after the gradients: the owner applies step `step` to its (already current) row.  One extra workgroup
 // (blockIdx == ceil(B/4)) runs hsk_finish_block when `fin.loss_b` is set.
-template <int V, int NCH, bool FULL>
+template <int V, int NCH, bool FULL, bool GEN>
 __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw, float* __restrict__ mU,
                                                           float* __restrict__ vU, float* __restrict__ Ub,
                                                           float* __restrict__ mUb, float* __restrict__ vUb,
@@ -475,14 +475,14 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
 #pragma unroll
   for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
-    for (int q = 0; q < V; ++q) hsk_adamw_update(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], c);
+    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], c);
   hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
   hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
   hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
   if (lane == 0) {
     if (Ub) {
       float pb = Ub[row], mb = mUb[row], vb = vUb[row];
-      hsk_adamw_update(pb, mb, vb, 0.f, c);
+      hsk_adamw_update<GEN>(pb, mb, vb, 0.f, c);
       Ub[row] = pb;
       mUb[row] = mb;
       vUb[row] = vb;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
 }
 
 // bring every row with last_step < step up to `step` (one workgroup per table row)
-template <int VV>
+template <int VV, bool GEN>
 __global__ __launch_bounds__(256) void k_user_flush(float* __restrict__ Uw, float* __restrict__ mU,
                                                     float* __restrict__ vU, float* __restrict__ Ub,
                                                     float* __restrict__ mUb, float* __restrict__ vUb,
@@ -504,13 +504,13 @@ __global__ __launch_bounds__(256) void k_user_flush(float* __restrict__ Uw, floa
   const int row = blockIdx.x;
   const int done = last_step[row];
   if (done >= step) return;
-  hsk_row_replay_wg<VV>(Uw + (long long)row * D, mU + (long long)row * D, vU + (long long)row * D, D, done, step, c,
-                        tab, tab_len);
+  hsk_row_replay_wg<VV, GEN>(Uw + (long long)row * D, mU + (long long)row * D, vU + (long long)row * D, D, done, step, c,
+                             tab, tab_len);
   __syncthreads();
   if (threadIdx.x == 0) {
     if (Ub) {
       float pb = Ub[row], mb = mUb[row], vb = vUb[row];
-      for (int t = done + 1; t <= step; ++t) hsk_adamw_update(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
+      for (int t = done + 1; t <= step; ++t) hsk_adamw_update<GEN>(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
       Ub[row] = pb;
       mUb[row] = mb;
       vUb[row] = vb;

@@ -106,7 +106,8 @@ class ShardedBprMf:
 
     def __init__(self, comm: Comm, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  batch, n_neg, csr_indptr, csr_indices, coo_user, coo_item, seed=0, beta1=ADAM_BETA1,
-                 beta2=ADAM_BETA2, eps=ADAM_EPS, capacity: Optional[int] = None, loss='bpr', log_adjust=0.0, alias=None):
+                 beta2=ADAM_BETA2, eps=None, capacity: Optional[int] = None, loss='bpr', log_adjust=0.0, alias=None,
+                 optimizer='adamw'):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.comm = comm
@@ -166,7 +167,8 @@ class ShardedBprMf:
             setattr(st, 'm_' + k, _p(self.m[k]))
             setattr(st, 'v_' + k, _p(self.v[k]))
         st.n_users, st.n_items, st.dim = U_loc, I, D
-        st.lr, st.beta1, st.beta2, st.eps, st.wd = lr, beta1, beta2, eps, wd
+        st.lr, st.beta1, st.beta2, st.eps, st.wd = lr, beta1, beta2, hip_ops.opt_eps(optimizer, eps), wd
+        st.opt_kind = hip_ops.OPT_KINDS[optimizer]
         st.step = 0
         st.csr_indptr, st.csr_indices = _p(csr_indptr), _p(csr_indices)
         st.coo_user, st.coo_item, st.nnz = _p(coo_user), _p(coo_item), coo_user.numel()
@@ -177,7 +179,7 @@ class ShardedBprMf:
         st.timing_mask, st.timing, st.aux, st.timing_every, st.timing_now = 0, None, None, 1, 0
         if loss == 'bce' and (user_bias is not None or global_bias is not None):
             raise ValueError('the fused bce step treats user/global bias as gradient-free')
-        st.loss_kind, st.reserved1, st.ssm_log_adjust = hip_ops.LOSS_KINDS[loss], 0, float(log_adjust)
+        st.loss_kind, st.ssm_log_adjust = hip_ops.LOSS_KINDS[loss], float(log_adjust)
         self.alias = alias
         st.alias_prob, st.alias_idx = (None, None) if alias is None else (_p(alias[0]), _p(alias[1]))
         st.loss_out, st.status = _p(self.loss_out), _p(self.status)

@@ -158,6 +158,32 @@ def adamw_dense(p, g, m, v, lr, wd, step, beta1=ADAM_BETA1, beta2=ADAM_BETA2, ep
                'hsk_adamw_dense')
 
 
+OPT_KINDS = {'adamw': 0, 'adam': 1, 'adagrad': 2}            # HSK_OPT_* (conf['optimizer'], train/trainer.py:48-53)
+ADAGRAD_EPS = 1e-10                                           # torch.optim.Adagrad default
+
+
+def opt_eps(optimizer: str, eps=None) -> float:
+    """torch's default eps of the optimiser unless given."""
+    if eps is not None:
+        return eps
+    return ADAGRAD_EPS if optimizer == 'adagrad' else ADAM_EPS
+
+
+def opt_dense(optimizer, p, g, m, v, lr, wd, step, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=None):
+    """In-place dense step of 'adamw' | 'adam' | 'adagrad' (torch.optim defaults; weight_decay = L2 for the last
+    two).  v is exp_avg_sq / adagrad's state_sum; step is 1-based."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    if optimizer not in OPT_KINDS:
+        raise ValueError(f'Optimizer {optimizer} not yet implemented')
+    _chk(p, torch.float32, 'p')
+    _chk(m, torch.float32, 'm', tuple(p.shape))
+    _chk(v, torch.float32, 'v', tuple(p.shape))
+    _chk(g, torch.float32, 'g', tuple(p.shape), optional=True)
+    _lib.check(lib.hsk_opt_dense(OPT_KINDS[optimizer], _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2,
+                                 opt_eps(optimizer, eps), wd, step, _stream()), 'hsk_opt_dense')
+
+
 def build_alias_table(p):
     """Walker/Vose alias table of a discrete distribution p (host, float64) -> (prob float32 [n], alias int32 [n]):
     draw a uniform column j, keep j with probability prob[j], else take alias[j]."""
@@ -215,10 +241,13 @@ class BprMfFusedState:
     """
 
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
-                 max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, seed=0,
+                 max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=None, seed=0,
                  csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=True,
-                 loss='bpr', log_adjust=0.0, alias=None):
+                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw'):
         _lib.require_gpu()
+        if optimizer not in OPT_KINDS:
+            raise ValueError(f'Optimizer {optimizer} not yet implemented')
+        eps = opt_eps(optimizer, eps)
         self.lib = _lib.load()
         n_users, dim = user_emb.shape
         n_items = item_emb.shape[0]
@@ -256,6 +285,7 @@ class BprMfFusedState:
             setattr(st, 'v_' + k, _p(self.v[k]))
         st.n_users, st.n_items, st.dim = n_users, n_items, dim
         st.lr, st.beta1, st.beta2, st.eps, st.wd = lr, beta1, beta2, eps, wd
+        st.opt_kind = OPT_KINDS[optimizer]
         st.step = 0
         st.csr_indptr, st.csr_indices = _p(csr_indptr), _p(csr_indices)
         st.coo_user, st.coo_item = _p(coo_user), _p(coo_item)
@@ -270,7 +300,7 @@ class BprMfFusedState:
             raise ValueError(f'unknown loss {loss!r}')
         if loss == 'bce' and (user_bias is not None or global_bias is not None):
             raise ValueError('the fused bce step treats user/global bias as gradient-free; use the autograd path')
-        st.loss_kind, st.reserved1, st.ssm_log_adjust = LOSS_KINDS[loss], 0, float(log_adjust)
+        st.loss_kind, st.ssm_log_adjust = LOSS_KINDS[loss], float(log_adjust)
         self.alias = alias   # (prob f32 [I], idx i32 [I]) for train_neg_strategy 'popular', None = uniform
         if alias is not None:
             _chk(alias[0], torch.float32, 'alias prob', (n_items,))

@@ -52,7 +52,7 @@ class Trainer:
         self.sharded = None   # hassaku_amd.dist.ShardedBprMf when launched with one process per GPU
         self.comm = None
         want_fused = conf.get('fused_step', True)
-        fusable = (isinstance(model, SGDMatrixFactorization) and conf['optimizer'] == 'adamw'
+        fusable = (isinstance(model, SGDMatrixFactorization) and conf['optimizer'] in hip_ops.OPT_KINDS
                    and isinstance(rec_loss, (RecBayesianPersonalizedRankingLoss, RecBinaryCrossEntropy,
                                              RecSampledSoftmaxLoss)))
         if fusable and isinstance(rec_loss, RecBinaryCrossEntropy) and (model.use_user_bias or model.use_global_bias):
@@ -61,7 +61,7 @@ class Trainer:
         multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
         if multi:
             if not (fusable and isinstance(train_loader, TrainDataLoader)):
-                raise RuntimeError('multi-GPU training supports mf + {bpr, bce, sampled_softmax} + adamw with the '
+                raise RuntimeError('multi-GPU training supports mf + {bpr, bce, sampled_softmax} + {adamw, adam, adagrad} with the '
                                    'device TrainDataLoader (bce: without user / global bias)')
             self.sharded = self._build_sharded(conf)
             self.optimizer = None
@@ -97,7 +97,8 @@ class Trainer:
             seed = conf['running_settings'].get('seed', 64)
         return hip_ops.BprMfFusedState(user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd, max_batch=max_batch,
                                        max_cols=n_neg + 1, seed=seed, loss=self.rec_loss.kind,
-                                       log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0), **kw)
+                                       log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0),
+                                       optimizer=conf['optimizer'], **kw)
 
     def _build_sharded(self, conf):
         from hassaku_amd.dist import Comm, ShardedBprMf
@@ -108,7 +109,8 @@ class Trainer:
         return ShardedBprMf(self.comm, user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd,
                             batch=loader.batch_size, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed,
                             loss=self.rec_loss.kind, log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0),
-                            alias=loader.interaction_sampler.alias(torch.device(self.device)), **arrays)
+                            alias=loader.interaction_sampler.alias(torch.device(self.device)),
+                            optimizer=conf['optimizer'], **arrays)
 
     def _sync_model_from_shards(self):
         """Assemble the row-sharded user table into the model's parameters (every rank), e.g. before saving."""

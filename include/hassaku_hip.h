@@ -34,6 +34,13 @@ enum {
 /* loss kinds (hsk_bprmf_state.loss_kind, hsk_rec_loss_grad) */
 enum { HSK_LOSS_BPR = 0, HSK_LOSS_BCE = 1, HSK_LOSS_SSM = 2 };
 
+/* optimiser kinds (conf['optimizer'], train/trainer.py:48-53) */
+enum {
+  HSK_OPT_ADAMW = 0,
+  HSK_OPT_ADAM = 1,
+  HSK_OPT_ADAGRAD = 2
+};
+
 /* bits of the device-side status word */
 enum {
   HSK_STATUS_BAD_INDEX = 1,       /* an index was outside [0, n) and was clamped */
@@ -104,6 +111,17 @@ int hsk_mf_backward(const float* user_emb, const float* item_emb,
 int hsk_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n,
                     double lr, double beta1, double beta2, double eps, double wd, int64_t step,
                     hsk_stream_t stream);
+
+/*
+ * The same for any of the three optimisers train/trainer.py:48-53 can select (torch defaults otherwise):
+ *   HSK_OPT_ADAMW    as above
+ *   HSK_OPT_ADAM     torch.optim.Adam, weight_decay as L2: g += wd*p, then the Adam update without decay
+ *   HSK_OPT_ADAGRAD  torch.optim.Adagrad (lr_decay 0, initial accumulator 0): g += wd*p; v += g*g;
+ *                    p -= lr * g / (sqrt(v) + eps); v = state_sum; m keeps its values but must be valid memory
+ */
+int hsk_opt_dense(int opt_kind, float* p, const float* g, float* m, float* v, int64_t n,
+                  double lr, double beta1, double beta2, double eps, double wd, int64_t step,
+                  hsk_stream_t stream);
 
 /*
  * Uniform negative sampling with rejection of the user's training positives.
@@ -181,7 +199,10 @@ typedef struct hsk_bprmf_state {
   /* recommendation loss of the fused step (train/rec_losses.py): HSK_LOSS_BPR (default, 0), HSK_LOSS_BCE,
      HSK_LOSS_SSM (sampled softmax; ssm_log_adjust = log(n_items / neg_train) for uniform sampling, else 0) */
   int32_t loss_kind;
-  int32_t reserved1;
+  /* optimiser selected by conf['optimizer'] (train/trainer.py:48-53): HSK_OPT_ADAMW (default, 0), HSK_OPT_ADAM,
+     HSK_OPT_ADAGRAD.  m_* = exp_avg (unused by adagrad, must still be valid memory), v_* = exp_avg_sq /
+     adagrad's state_sum.  torch defaults: eps 1e-8 (adam, adamw), 1e-10 (adagrad); betas only for adam / adamw */
+  int32_t opt_kind;
   double ssm_log_adjust;
   /* negative sampling law of the device sampler: NULL = uniform; otherwise a Walker alias table over the items
      (alias_prob float[I], alias_idx int32[I]) = train_neg_strategy 'popular' (data/dataloader.py:59-64) */

@@ -168,6 +168,45 @@ void orc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, dou
   }
 }
 
+/* torch.optim.Adam single-tensor step as train/trainer.py:48-49 configures it (weight_decay = L2):
+ *   g = g.add(p, alpha=wd); m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, value=1-b2);
+ *   denom = v.sqrt()/sqrt(1-b2^t) + eps; p.addcdiv_(m, denom, value=-(lr/(1-b1^t)))          (no decoupled decay) */
+void orc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
+                   double eps, double wd, int64_t step) {
+  const float fwd = (float)wd;
+  const float w1 = (float)(1.0 - b1);
+  const float fb2 = (float)b2;
+  const float w2 = (float)(1.0 - b2);
+  const float step_size = (float)(lr / (1.0 - pow(b1, (double)step)));
+  const float bc2s = (float)sqrt(1.0 - pow(b2, (double)step));
+  const float feps = (float)eps;
+  for (int64_t i = 0; i < n; ++i) {
+    float gi = g ? g[i] : 0.f;
+    gi = fmaf(fwd, p[i], gi);   /* ATen's add(alpha) kernel is vec::fmadd(b, alpha, a) */
+    float mi = m[i] + w1 * (gi - m[i]);
+    float vi = v[i] * fb2;
+    vi = vi + (w2 * gi) * gi;
+    const float denom = sqrtf(vi) / bc2s + feps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi;
+  }
+}
+
+/* torch.optim.Adagrad single-tensor step as train/trainer.py:50-51 configures it (lr_decay 0, accumulator 0, eps 1e-10):
+ *   g = g.add(p, alpha=wd); clr = lr; state_sum.addcmul_(g, g, value=1); std = state_sum.sqrt().add_(eps);
+ *   p.addcdiv_(g, std, value=-clr) */
+void orc_adagrad_step(float* p, const float* g, float* sum, int64_t n, double lr, double eps, double wd) {
+  const float fwd = (float)wd, clr = (float)lr, feps = (float)eps;
+  for (int64_t i = 0; i < n; ++i) {
+    float gi = g ? g[i] : 0.f;
+    gi = fmaf(fwd, p[i], gi);   /* ATen's add(alpha) kernel is vec::fmadd(b, alpha, a) */
+    const float si = sum[i] + gi * gi;
+    const float std = sqrtf(si) + feps;
+    p[i] = p[i] - clr * (gi / std);
+    sum[i] = si;
+  }
+}
+
 /* data/dataloader.py:114-124 invariant checker: every negative is in [0,n_items) and not in the
  * user's CSR row.  Returns the number of violations. */
 int64_t orc_count_bad_negatives(const int64_t* indptr, const int32_t* indices, int64_t n_items,

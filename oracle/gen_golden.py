@@ -16,6 +16,8 @@ Fixtures (data only: inputs and the reference's outputs):
   g4_fit.npz          reference Trainer.fit for 2 epochs with the reference loader (seed 64, 0 workers):
                       the batch stream, per-epoch losses, final parameters, validation metrics
   g5_metrics.npz      precision/recall/ndcg_at_k_batch on random logits/labels
+  g8_opt_<tag>.npz    G1's protocol with torch.optim.Adam / torch.optim.Adagrad (conf['optimizer'] = adam | adagrad,
+                      train/trainer.py:48-51): params after steps 1 and 3, exp_avg / exp_avg_sq or state_sum
   g7_checkpoint/      a checkpoint directory as the reference leaves it on disk: model.pth written by
                       save_model_to_path, conf.yml written by save_yaml after parse_conf, and expected.npz =
                       the saved tensors + the reference model's logits on a fixed (u, i) batch after
@@ -320,6 +322,55 @@ def gen_g5():
     print('g5 ok')
 
 
+def gen_g8():
+    from algorithms.sgd_alg import SGDMatrixFactorization
+    from train.rec_losses import RecBayesianPersonalizedRankingLoss
+    cases = [('adam_d32_item', 'adam', 32, 40, 130, 16, 7, False, True, False, 3e-4, 1e-3),
+             ('adam_d64_all', 'adam', 64, 40, 130, 16, 7, True, True, True, 3e-4, 1e-3),
+             ('adagrad_d32_item', 'adagrad', 32, 40, 130, 16, 7, False, True, False, 1e-2, 1e-3),
+             ('adagrad_d402_all', 'adagrad', 402, 24, 110, 8, 4, True, True, True, 1e-2, 1e-3)]
+    for tag, opt_name, D, U, I, B, N, ub, ib, gb, lr, wd in cases:
+        torch.manual_seed(64)
+        model = SGDMatrixFactorization(U, I, D, ub, ib, gb)
+        loss_fn = RecBayesianPersonalizedRankingLoss()
+        cls = {'adam': torch.optim.Adam, 'adagrad': torch.optim.Adagrad}[opt_name]
+        opt = cls(model.parameters(), lr=lr, weight_decay=wd)             # exactly train/trainer.py:48-51
+        rng = np.random.RandomState(11)
+        fx = {'lr': lr, 'wd': wd, 'n_users': U, 'n_items': I, 'dim': D, 'optimizer': opt_name,
+              'use_user_bias': ub, 'use_item_bias': ib, 'use_global_bias': gb}
+        for k, v in state_np(model).items():
+            fx['init.' + k] = v
+        for step in range(1, 4):
+            u = torch.from_numpy(rng.randint(0, U, size=B).astype(np.int64))
+            i = torch.from_numpy(rng.randint(0, I, size=(B, 1 + N)).astype(np.int64))
+            labels = torch.zeros((B, 1 + N), dtype=torch.float64)
+            labels[:, 0] = 1.
+            out = model(u, i)
+            loss = loss_fn.compute_loss(out, labels)
+            total = loss + model.get_and_reset_other_loss()['reg_loss']
+            total.backward()
+            fx[f's{step}.u_idx'] = u.numpy()
+            fx[f's{step}.i_idx'] = i.numpy()
+            fx[f's{step}.loss'] = np.array(loss.item(), dtype=np.float64)
+            if step == 1:
+                for name, p in model.named_parameters():
+                    fx['s1.grad.' + name] = p.grad.numpy().copy()
+            opt.step()
+            opt.zero_grad()
+            if step in (1, 3):
+                for k, v in state_np(model).items():
+                    fx[f's{step}.param.' + k] = v
+                for name, p in model.named_parameters():
+                    st = opt.state[p]
+                    if opt_name == 'adagrad':
+                        fx[f's{step}.v.' + name] = st['sum'].detach().numpy().copy()
+                    else:
+                        fx[f's{step}.m.' + name] = st['exp_avg'].detach().numpy().copy()
+                        fx[f's{step}.v.' + name] = st['exp_avg_sq'].detach().numpy().copy()
+        np.savez_compressed(os.path.join(OUT, f'g8_opt_{tag}.npz'), **fx)
+        print('g8', tag, 'ok')
+
+
 def gen_g7():
     from algorithms.algorithms_utils import AlgorithmsEnum
     from algorithms.sgd_alg import SGDMatrixFactorization
@@ -363,3 +414,4 @@ if __name__ == '__main__':
     gen_g5()
     gen_g6()
     gen_g7()
+    gen_g8()

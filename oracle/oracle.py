@@ -113,6 +113,24 @@ def adamw_step(p, g, m, v, lr, wd, step, b1=0.9, b2=0.999, eps=1e-8):
                          c_double(eps), c_double(wd), c_int64(step))
 
 
+def opt_step(optimizer, p, g, m, v, lr, wd, step, b1=0.9, b2=0.999, eps=None):
+    """One step of torch.optim.{AdamW, Adam, Adagrad} with the reference's settings (train/trainer.py:48-53), in place.
+    v is exp_avg_sq or adagrad's state_sum; m is untouched by adagrad."""
+    if optimizer == 'adamw':
+        return adamw_step(p, g, m, v, lr, wd, step, b1, b2, 1e-8 if eps is None else eps)
+    for a in (p, m, v):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    g = _f32(g)
+    if optimizer == 'adam':
+        lib().orc_adam_step(_p(p), _p(g), _p(m), _p(v), c_int64(p.size), c_double(lr), c_double(b1), c_double(b2),
+                            c_double(1e-8 if eps is None else eps), c_double(wd), c_int64(step))
+    elif optimizer == 'adagrad':
+        lib().orc_adagrad_step(_p(p), _p(g), _p(v), c_int64(p.size), c_double(lr),
+                               c_double(1e-10 if eps is None else eps), c_double(wd))
+    else:
+        raise ValueError(optimizer)
+
+
 class MfOracleTrainer:
     """Dense restatement of one Trainer.fit step (train/trainer.py:128-148) for MF + BPR + AdamW.
 
@@ -120,8 +138,8 @@ class MfOracleTrainer:
     s_pos - s_neg; the reference's ~1e-9 autograd noise there is amplified by Adam and is not part
     of the contract -- SURVEY.md section 7, hard part 2)."""
 
-    def __init__(self, U, I, Ib=None, Ub=None, gb=None, lr=1e-3, wd=0.0, loss='bpr', log_adjust=0.0):
-        self.loss, self.log_adjust = loss, log_adjust
+    def __init__(self, U, I, Ib=None, Ub=None, gb=None, lr=1e-3, wd=0.0, loss='bpr', log_adjust=0.0, optimizer='adamw'):
+        self.loss, self.log_adjust, self.optimizer = loss, log_adjust, optimizer
         self.P = {'user_emb': _f32(U).copy(), 'item_emb': _f32(I).copy()}
         if Ib is not None:
             self.P['item_bias'] = _f32(Ib).reshape(-1).copy()
@@ -150,7 +168,7 @@ class MfOracleTrainer:
         grads = {'user_emb': gU, 'item_emb': gI, 'item_bias': gIb, 'user_bias': gUb, 'global_bias': ggb}
         self.t += 1
         for k in P:
-            adamw_step(P[k], grads[k], self.M[k], self.V[k], self.lr, self.wd, self.t)
+            opt_step(self.optimizer, P[k], grads[k], self.M[k], self.V[k], self.lr, self.wd, self.t)
         return loss, logits, g, grads
 
 

@@ -198,14 +198,14 @@ def test_cpu_tensors_are_refused(ops):
                       torch.zeros((1, 2), dtype=torch.int64))
 
 
-def _run_random_steps(ops, n_steps, lazy, seed=5, U=300, I=200, D=64, B=48, N=9, bias=True):
+def _run_random_steps(ops, n_steps, lazy, seed=5, U=300, I=200, D=64, B=48, N=9, bias=True, **kw):
     rng = np.random.RandomState(seed)
     P = {'user_emb': (rng.randn(U, D) * 0.05).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.05).astype(np.float32),
          'item_bias': (rng.randn(I) * 0.1).astype(np.float32)}
     if bias:
         P['user_bias'] = (rng.randn(U) * 0.1).astype(np.float32)
         P['global_bias'] = np.array([0.3], np.float32)
-    st, t = _fused_state(ops, P, 2e-3, 1e-4, B, N + 1, lazy_users=lazy)
+    st, t = _fused_state(ops, P, 2e-3, 1e-4, B, N + 1, lazy_users=lazy, **kw)
     losses = []
     for s in range(n_steps):
         u = rng.randint(0, U, size=B).astype(np.int64)

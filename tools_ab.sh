@@ -2,7 +2,7 @@
 # A/B helper: run bench.py with every stage timed under different env settings and print one line each.
 # usage: tools_ab.sh "NAME=VAL ..." "NAME=VAL ..." ...   (each argument is one configuration; "" = defaults)
 for cfg in "$@"; do
-  out=$(env $cfg timeout -k 10 300 python bench.py --steps 128 --warmup 10 --cpu-budget 0 --time-all-stages 2>&1 | tail -1)
+  out=$(env $cfg timeout -k 10 300 python bench.py --steps 128 --warmup 10 --cpu-budget 0 --time-all-stages $ABFLAGS 2>&1 | tail -1)
   echo "$out" | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
