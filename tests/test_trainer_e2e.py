@@ -169,3 +169,34 @@ def test_run_train_val_test_end_to_end(tmp_path):
     assert len(test) == 36 and 'group_1_ndcg@100' in test and 0 < test['ndcg@10'] <= 1
     for k in ('epoch_train_loss', 'epoch_train_rec_loss', 'epoch_train_reg_loss'):
         pass  # per-epoch keys are printed/logged by Trainer.fit; best_metrics holds the validation dict
+
+
+@pytest.mark.parametrize('opt,lr', [('adam', 5e-3), ('adagrad', 5e-2)])
+def test_conf_optimizer_adam_adagrad_train_on_the_fused_step(tmp_path, opt, lr):
+    """conf['optimizer'] = adam | adagrad (train/trainer.py:48-51): same driver, fused HIP step, and it learns."""
+    from hassaku_amd.algorithms.algorithms_utils import AlgorithmsEnum
+    from hassaku_amd.data.data_utils import DatasetsEnum
+    from hassaku_amd.data.synthetic import generate, write_csv_dataset
+    from hassaku_amd.experiment_helper import run_train_val_test
+    from hassaku_amd.train import trainer as trainer_mod
+    ds_path = str(tmp_path / 'data' / 'ml100k' / 'processed_dataset')
+    write_csv_dataset(generate(300, 400, 12000, seed=2, n_groups=0), ds_path)
+    conf = {'data_path': str(tmp_path / 'data'), 'model_save_path': str(tmp_path / 'models'), 'embedding_dim': 64,
+            'lr': lr, 'wd': 1e-5, 'use_user_bias': False, 'use_item_bias': True, 'use_global_bias': False,
+            'optimizer': opt, 'n_epochs': 6, 'max_patience': 5, 'train_batch_size': 128, 'neg_train': 10,
+            'rec_loss': 'bpr', 'eval_batch_size': 256, 'device': 'cuda',
+            'running_settings': {'use_wandb': False, 'train_n_workers': 0, 'batch_verbose': False}}
+    built = []
+    orig = trainer_mod.Trainer._build_fused
+
+    def spy(self, c):
+        built.append(c['optimizer'])
+        return orig(self, c)
+
+    trainer_mod.Trainer._build_fused = spy
+    try:
+        best, test, conf = run_train_val_test(AlgorithmsEnum.mf, DatasetsEnum.ml100k, conf)
+    finally:
+        trainer_mod.Trainer._build_fused = orig
+    assert built == [opt]                      # the fused state was built for this optimiser (no autograd fallback)
+    assert best['ndcg@10'] > 0.02 and 0 < test['ndcg@10'] <= 1
