@@ -50,6 +50,70 @@ class _MFScores(torch.autograd.Function):
                 g_gb, None, None, None)
 
 
+class _BiasScores(torch.autograd.Function):
+    """logits = ub[u] + ib[i] + gb through hsk_mf_scores(dim=0); backward = hsk_mf_backward(dim=0)."""
+
+    @staticmethod
+    def forward(ctx, item_bias, user_bias, global_bias, u_idxs, i_idxs, status):
+        out = hip_ops.bias_scores(item_bias.view(-1), user_bias.view(-1), global_bias, u_idxs, i_idxs, status)
+        ctx.save_for_backward(u_idxs, i_idxs)
+        ctx.sizes = (user_bias.shape[0], item_bias.shape[0])
+        ctx.status = status
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        u_idxs, i_idxs = ctx.saved_tensors
+        n_users, n_items = ctx.sizes
+        g_ib, g_ub, g_gb = hip_ops.bias_backward(n_users, n_items, u_idxs, i_idxs, grad_out.contiguous(), True,
+                                                 ctx.status)
+        return g_ib.view(-1, 1), g_ub.view(-1, 1), g_gb, None, None, None
+
+
+class SGDBaseline(SGDBasedRecommenderAlgorithm):
+    """Global + user + item bias (algorithms/sgd_alg.py:72-107 of the reference): same constructor, parameter names
+    (user_bias.weight [U,1], item_bias.weight [I,1], global_bias [1]) and initialisation order."""
+
+    def __init__(self, n_users: int, n_items: int):
+        super().__init__()
+        self.n_users, self.n_items = n_users, n_items
+        self.user_bias = nn.Embedding(n_users, 1)
+        self.item_bias = nn.Embedding(n_items, 1)
+        self.global_bias = nn.Parameter(torch.zeros(1), requires_grad=True)
+        self.apply(general_weight_init)
+        self.name = 'SGDBaseline'
+        self._status: Optional[torch.Tensor] = None
+        logging.info('Built %s (HIP)', self.name)
+
+    def status_word(self) -> torch.Tensor:
+        dev = self.item_bias.weight.device
+        if self._status is None or self._status.device != dev:
+            self._status = hip_ops.new_status(dev)
+        return self._status
+
+    def check_indices(self):
+        if self._status is not None:
+            hip_ops.raise_on_status(self._status, self.name)
+            self._status.zero_()
+
+    def get_user_representations(self, u_idxs: torch.Tensor) -> UserRepr:
+        return UserRepr(u_idxs)
+
+    def get_item_representations(self, i_idxs: torch.Tensor) -> ItemRepr:
+        return ItemRepr(i_idxs)
+
+    def combine_user_item_representations(self, u_repr: UserRepr, i_repr: ItemRepr) -> torch.Tensor:
+        u_idxs, i_idxs = u_repr.u_idxs, i_repr.i_idxs
+        if i_idxs.dim() == 1:   # evaluation form (eval/eval.py:240-248): every user against the item list
+            i_idxs = i_idxs.unsqueeze(0).expand(u_idxs.numel(), -1)
+        return _BiasScores.apply(self.item_bias.weight, self.user_bias.weight, self.global_bias, u_idxs.contiguous(),
+                                 i_idxs.contiguous(), self.status_word())
+
+    @staticmethod
+    def build_from_conf(conf: dict, dataset):
+        return SGDBaseline(dataset.n_users, dataset.n_items)
+
+
 class SGDMatrixFactorization(SGDBasedRecommenderAlgorithm):
     """Matrix factorisation scored by dot product (+ optional user / item / global bias)."""
 

@@ -62,15 +62,62 @@ __global__ __launch_bounds__(256) void k_scores(const float* __restrict__ Uw, co
   }
 }
 
+// dim == 0: the bias-only model (SGDBaseline, algorithms/sgd_alg.py:72-107): out = ub[u] + ib[i] + gb, one thread per logit
+__global__ __launch_bounds__(256) void k_bias_scores(const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                     const float* __restrict__ gb, int n_users, int n_items,
+                                                     const int64_t* __restrict__ u_idx,
+                                                     const int64_t* __restrict__ i_idx, long long B, long long K,
+                                                     float* __restrict__ out, int32_t* status) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * K) return;
+  const int u = hsk_clamp_index(u_idx[e / K], n_users, status);
+  const int it = hsk_clamp_index(i_idx[e], n_items, status);
+  // the reference's order: u_repr + i_repr + global_bias
+  float s = Ub ? Ub[u] : 0.f;
+  s = s + (Ib ? Ib[it] : 0.f);
+  if (gb) s = s + gb[0];
+  out[e] = s;
+}
+
+// gradients of the bias-only model: one wave per row b (sums its K logit gradients for ub[u_b] and gb)
+__global__ __launch_bounds__(256) void k_bias_backward(int n_users, int n_items, const int64_t* __restrict__ u_idx,
+                                                       const int64_t* __restrict__ i_idx, int B, long long K,
+                                                       const float* __restrict__ gl, float* __restrict__ gIb,
+                                                       float* __restrict__ gUb, float* __restrict__ ggb,
+                                                       int32_t* status) {
+  const int lane = hsk_lane();
+  const int b = blockIdx.x * 4 + hsk_uniform_i(threadIdx.x >> 6);
+  if (b >= B) return;
+  float gsum = 0.f;
+  for (long long k = lane; k < K; k += 64) {
+    const float g = gl[(long long)b * K + k];
+    gsum += g;
+    if (gIb) atomicAdd(&gIb[hsk_clamp_index(i_idx[(long long)b * K + k], n_items, status)], g);
+  }
+  const float gs = hsk_wave_sum(gsum);
+  if (lane == 0) {
+    if (gUb) atomicAdd(&gUb[hsk_clamp_index(u_idx[b], n_users, status)], gs);
+    if (ggb) atomicAdd(ggb, gs);
+  }
+}
+
 extern "C" int hsk_mf_scores(const float* user_emb, const float* item_emb, const float* item_bias,
                              const float* user_bias, const float* global_bias, int64_t n_users, int64_t n_items,
                              int64_t dim, const int64_t* u_idx, const int64_t* i_idx, int64_t batch, int64_t n_cols,
                              float* logits, int32_t* status, hsk_stream_t stream_) {
-  HSK_REQUIRE(user_emb && item_emb && u_idx && i_idx && logits, HSK_ERR_INVALID, "NULL pointer argument");
-  HSK_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && batch >= 0 && n_cols >= 0, HSK_ERR_INVALID, "bad sizes");
+  HSK_REQUIRE(u_idx && i_idx && logits, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_users > 0 && n_items > 0 && dim >= 0 && batch >= 0 && n_cols >= 0, HSK_ERR_INVALID, "bad sizes");
+  HSK_REQUIRE(dim == 0 || (user_emb && item_emb), HSK_ERR_INVALID, "embedding tables must not be NULL when dim > 0");
   HSK_REQUIRE(batch <= 65535, HSK_ERR_UNSUPPORTED, "batch %lld > 65535 rows per call", (long long)batch);
   if (batch == 0 || n_cols == 0) return HSK_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  if (dim == 0) {
+    k_bias_scores<<<(unsigned)hsk_ceil_div(batch * n_cols, 256), 256, 0, stream>>>(
+        item_bias, user_bias, global_bias, (int)n_users, (int)n_items, u_idx, i_idx, (long long)batch, (long long)n_cols,
+        logits, status);
+    HSK_LAUNCH_CHECK();
+    return HSK_OK;
+  }
   int rc = hsk_dispatch_dim(dim, [&](auto v_, auto n_, auto f_) {
     constexpr int V = decltype(v_)::value;
     constexpr int NCH = decltype(n_)::value;
@@ -222,10 +269,22 @@ extern "C" int hsk_mf_backward(const float* user_emb, const float* item_emb, int
                                int64_t dim, const int64_t* u_idx, const int64_t* i_idx, int64_t batch, int64_t n_cols,
                                const float* grad_logits, float* g_user_emb, float* g_item_emb, float* g_item_bias,
                                float* g_user_bias, float* g_global_bias, int32_t* status, hsk_stream_t stream_) {
-  HSK_REQUIRE(user_emb && item_emb && u_idx && i_idx && grad_logits, HSK_ERR_INVALID, "NULL pointer argument");
-  HSK_REQUIRE(n_users > 0 && n_items > 0 && dim > 0 && batch >= 0 && n_cols >= 0, HSK_ERR_INVALID, "bad sizes");
+  HSK_REQUIRE(u_idx && i_idx && grad_logits, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_users > 0 && n_items > 0 && dim >= 0 && batch >= 0 && n_cols >= 0, HSK_ERR_INVALID, "bad sizes");
+  HSK_REQUIRE(dim == 0 || (user_emb && item_emb), HSK_ERR_INVALID, "embedding tables must not be NULL when dim > 0");
   HSK_REQUIRE(batch <= 65535, HSK_ERR_UNSUPPORTED, "batch %lld > 65535 rows per call", (long long)batch);
   hipStream_t stream = (hipStream_t)stream_;
+  if (dim == 0) {   // bias-only model
+    if (g_item_bias) HSK_HIP(hipMemsetAsync(g_item_bias, 0, (size_t)n_items * 4, stream));
+    if (g_user_bias) HSK_HIP(hipMemsetAsync(g_user_bias, 0, (size_t)n_users * 4, stream));
+    if (g_global_bias) HSK_HIP(hipMemsetAsync(g_global_bias, 0, 4, stream));
+    if (batch == 0 || n_cols == 0) return HSK_OK;
+    k_bias_backward<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>((int)n_users, (int)n_items, u_idx, i_idx,
+                                                                          (int)batch, (long long)n_cols, grad_logits,
+                                                                          g_item_bias, g_user_bias, g_global_bias, status);
+    HSK_LAUNCH_CHECK();
+    return HSK_OK;
+  }
   if (g_user_emb) HSK_HIP(hipMemsetAsync(g_user_emb, 0, (size_t)n_users * dim * 4, stream));
   if (g_item_emb) HSK_HIP(hipMemsetAsync(g_item_emb, 0, (size_t)n_items * dim * 4, stream));
   if (g_item_bias) HSK_HIP(hipMemsetAsync(g_item_bias, 0, (size_t)n_items * 4, stream));

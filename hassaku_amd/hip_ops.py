@@ -146,6 +146,46 @@ def mf_backward(user_emb, item_emb, u_idx, i_idx, grad_logits, want_item_bias, w
     return g_u, g_i, g_ib, g_ub, g_gb
 
 
+def bias_scores(item_bias, user_bias, global_bias, u_idx, i_idx, status=None):
+    """Bias-only model (SGDBaseline, algorithms/sgd_alg.py:72-107): logits[b,k] = ub[u_b] + ib[i_bk] + gb."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(item_bias, torch.float32, 'item_bias')
+    _chk(user_bias, torch.float32, 'user_bias')
+    _chk(global_bias, torch.float32, 'global_bias', optional=True)
+    _chk(u_idx, torch.int64, 'u_idx')
+    _chk(i_idx, torch.int64, 'i_idx')
+    if u_idx.dim() != 1 or i_idx.dim() != 2 or i_idx.shape[0] != u_idx.shape[0]:
+        raise ValueError(f'u_idx {tuple(u_idx.shape)} / i_idx {tuple(i_idx.shape)}: expected [B] and [B,K]')
+    B, K = i_idx.shape
+    out = torch.empty((B, K), dtype=torch.float32, device=item_bias.device)
+    for lo in range(0, B, 65535):
+        hi = min(B, lo + 65535)
+        _lib.check(lib.hsk_mf_scores(None, None, _p(item_bias), _p(user_bias), _p(global_bias), user_bias.numel(),
+                                     item_bias.numel(), 0, _p(u_idx[lo:hi]), _p(i_idx[lo:hi]), hi - lo, K,
+                                     _p(out[lo:hi]), _p(status), _stream()), 'hsk_mf_scores')
+    return out
+
+
+def bias_backward(n_users, n_items, u_idx, i_idx, grad_logits, want_global_bias=True, status=None):
+    """Dense gradients of the bias-only model -> (g_item_bias [I], g_user_bias [U], g_global_bias [1] | None)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _chk(u_idx, torch.int64, 'u_idx')
+    _chk(i_idx, torch.int64, 'i_idx')
+    B, K = i_idx.shape
+    _chk(grad_logits, torch.float32, 'grad_logits', (B, K))
+    if B > 65535:
+        raise ValueError('bias_backward handles at most 65535 rows per call')
+    dev = grad_logits.device
+    g_ib = torch.empty(n_items, dtype=torch.float32, device=dev)
+    g_ub = torch.empty(n_users, dtype=torch.float32, device=dev)
+    g_gb = torch.empty(1, dtype=torch.float32, device=dev) if want_global_bias else None
+    _lib.check(lib.hsk_mf_backward(None, None, n_users, n_items, 0, _p(u_idx), _p(i_idx), B, K, _p(grad_logits), None,
+                                   None, _p(g_ib), _p(g_ub), _p(g_gb), _p(status), _stream()), 'hsk_mf_backward')
+    return g_ib, g_ub, g_gb
+
+
 def adamw_dense(p, g, m, v, lr, wd, step, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
     """In-place dense AdamW step (step is 1-based)."""
     _lib.require_gpu()

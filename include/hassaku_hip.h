@@ -63,6 +63,8 @@ int hsk_device_info(int32_t* cu_count, int32_t* wave_size, char* arch, int32_t a
  * SGDMatrixFactorization.get_user_representations / get_item_representations /
  * combine_user_item_representations (algorithms/sgd_alg.py:148-179).
  * Bias pointers may be NULL (bias disabled).  u_idx: [batch], i_idx: [batch, n_cols].
+ * dim == 0 (user_emb = item_emb = NULL) is the bias-only model SGDBaseline (algorithms/sgd_alg.py:72-107):
+ * logits = user_bias[u] + item_bias[i] + global_bias; hsk_mf_backward accepts the same form.
  */
 int hsk_mf_scores(const float* user_emb, const float* item_emb, const float* item_bias,
                   const float* user_bias, const float* global_bias,

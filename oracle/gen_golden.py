@@ -18,6 +18,8 @@ Fixtures (data only: inputs and the reference's outputs):
   g5_metrics.npz      precision/recall/ndcg_at_k_batch on random logits/labels
   g8_opt_<tag>.npz    G1's protocol with torch.optim.Adam / torch.optim.Adagrad (conf['optimizer'] = adam | adagrad,
                       train/trainer.py:48-51): params after steps 1 and 3, exp_avg / exp_avg_sq or state_sum
+  g9_sgdbias.npz      SGDBaseline (algorithms/sgd_alg.py:72-107) + RecBinaryCrossEntropy + AdamW, 3 steps: logits, loss,
+                      dense grads of step 1, parameters after steps 1 and 3
   g7_checkpoint/      a checkpoint directory as the reference leaves it on disk: model.pth written by
                       save_model_to_path, conf.yml written by save_yaml after parse_conf, and expected.npz =
                       the saved tensors + the reference model's logits on a fixed (u, i) batch after
@@ -371,6 +373,43 @@ def gen_g8():
         print('g8', tag, 'ok')
 
 
+def gen_g9():
+    from algorithms.sgd_alg import SGDBaseline
+    from train.rec_losses import RecBinaryCrossEntropy
+    U, I, B, N, lr, wd = 40, 130, 16, 7, 3e-3, 4e-5
+    torch.manual_seed(64)
+    model = SGDBaseline(U, I)
+    loss_fn = RecBinaryCrossEntropy()
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+    rng = np.random.RandomState(13)
+    fx = {'lr': lr, 'wd': wd, 'n_users': U, 'n_items': I}
+    for k, v in state_np(model).items():
+        fx['init.' + k] = v
+    for step in range(1, 4):
+        u = torch.from_numpy(rng.randint(0, U, size=B).astype(np.int64))
+        i = torch.from_numpy(rng.randint(0, I, size=(B, 1 + N)).astype(np.int64))
+        labels = torch.zeros((B, 1 + N), dtype=torch.float64)
+        labels[:, 0] = 1.
+        out = model(u, i)
+        loss = loss_fn.compute_loss(out, labels)
+        total = loss + model.get_and_reset_other_loss()['reg_loss']
+        total.backward()
+        fx[f's{step}.u_idx'] = u.numpy()
+        fx[f's{step}.i_idx'] = i.numpy()
+        fx[f's{step}.logits'] = out.detach().numpy().copy()
+        fx[f's{step}.loss'] = np.array(loss.item(), dtype=np.float64)
+        if step == 1:
+            for name, p in model.named_parameters():
+                fx['s1.grad.' + name] = p.grad.numpy().copy()
+        opt.step()
+        opt.zero_grad()
+        if step in (1, 3):
+            for k, v in state_np(model).items():
+                fx[f's{step}.param.' + k] = v
+    np.savez_compressed(os.path.join(OUT, 'g9_sgdbias.npz'), **fx)
+    print('g9 ok', sorted(k for k in fx if k.startswith('init.')))
+
+
 def gen_g7():
     from algorithms.algorithms_utils import AlgorithmsEnum
     from algorithms.sgd_alg import SGDMatrixFactorization
@@ -415,3 +454,4 @@ if __name__ == '__main__':
     gen_g6()
     gen_g7()
     gen_g8()
+    gen_g9()

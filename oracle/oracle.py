@@ -172,6 +172,34 @@ class MfOracleTrainer:
         return loss, logits, g, grads
 
 
+class BiasOracleTrainer:
+    """SGDBaseline (algorithms/sgd_alg.py:72-107): logits = ub[u] + ib[i] + gb, trained like MfOracleTrainer.
+    Gradients are summed in fp32 in the reference's order (index_add over the flattened batch)."""
+
+    def __init__(self, Ub, Ib, gb, lr=1e-3, wd=0.0, loss='bce', log_adjust=0.0, optimizer='adamw'):
+        self.P = {'user_bias': _f32(Ub).reshape(-1).copy(), 'item_bias': _f32(Ib).reshape(-1).copy(),
+                  'global_bias': _f32(gb).reshape(-1).copy()}
+        self.M = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.V = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.loss, self.log_adjust, self.optimizer, self.lr, self.wd, self.t = loss, log_adjust, optimizer, lr, wd, 0
+
+    def forward(self, u_idx, i_idx):
+        P = self.P
+        return ((P['user_bias'][u_idx][:, None] + P['item_bias'][i_idx]) + P['global_bias'][0]).astype(np.float32)
+
+    def step(self, u_idx, i_idx):
+        logits = self.forward(u_idx, i_idx)
+        loss, g = rec_loss_grad(self.loss, logits, self.log_adjust)
+        grads = {k: np.zeros_like(v) for k, v in self.P.items()}
+        np.add.at(grads['item_bias'], i_idx.reshape(-1), g.reshape(-1))
+        np.add.at(grads['user_bias'], u_idx, g.sum(axis=1, dtype=np.float32))
+        grads['global_bias'][0] = g.sum(dtype=np.float32)
+        self.t += 1
+        for k in self.P:
+            opt_step(self.optimizer, self.P[k], grads[k], self.M[k], self.V[k], self.lr, self.wd, self.t)
+        return loss, logits, g, grads
+
+
 def count_bad_negatives(indptr, indices, n_items, u_idx, neg):
     indptr, indices, u_idx, neg = _i64(indptr), _i32(indices), _i64(u_idx), _i64(neg)
     B, N = neg.shape
