@@ -33,6 +33,8 @@ WORKLOADS = {
     'ml100k': ('ml100k', 64, 1, 128),
     'ml1m': ('ml1m', 402, 50, 128),
     'ml10m': ('ml10m', 512, 100, 4096),
+    # not a BASELINE config: the ml10m step on tables that cannot be cached (the honest HBM point for k_fwd_ugrad)
+    'hbm': ('hbm', 512, 100, 4096),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROFILE_DIR = 'r1c_prefetch'  # committed rocprofv3 summaries of `bench.py` (profiles/README.md)

@@ -19,6 +19,7 @@ SHAPES = {
     'ml1m': (6040, 3706, 575_000),
     'ml10m': (69_878, 10_677, 8_000_000),
     'lfm2b': (16_384, 131_072, 2_000_000),
+    'hbm': (262_144, 2_000_000, 10_000_000),   # item table 4.1 GB at D=512: far beyond L2 + Infinity Cache
 }
 
 

@@ -33,11 +33,9 @@ def test_library_exports_every_declared_symbol():
     assert loaded.hsk_last_error() is not None
 
 
-def test_state_struct_layout_matches_header():
-    """Field order of the ctypes mirror == field order of `struct hsk_bprmf_state` in the header."""
-    from hassaku_amd._lib import HskBprmfState
+def _header_fields(struct_name):
     text = open(os.path.join(REPO, 'include', 'hassaku_hip.h')).read()
-    body = text[text.index('typedef struct hsk_bprmf_state {'):text.index('} hsk_bprmf_state;')]
+    body = text[text.index('typedef struct %s {' % struct_name):text.index('} %s;' % struct_name)]
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
     names = []
     for decl in body.split(';'):
@@ -50,7 +48,14 @@ def test_state_struct_layout_matches_header():
             m = re.search(r'([A-Za-z_][A-Za-z0-9_]*)\s*$', part.strip())
             if m:
                 names.append(m.group(1))
-    assert names == [f[0] for f in HskBprmfState._fields_]
+    return names
+
+
+def test_state_struct_layout_matches_header():
+    """Field order of the ctypes mirrors == field order of the structs in the header."""
+    from hassaku_amd._lib import HskBprmfMp, HskBprmfState
+    assert _header_fields('hsk_bprmf_state') == [f[0] for f in HskBprmfState._fields_]
+    assert _header_fields('hsk_bprmf_mp') == [f[0] for f in HskBprmfMp._fields_]
 
 
 def test_workspace_size_is_pure_host_arithmetic():
