@@ -244,7 +244,11 @@ def main():
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         out['cpu_baseline'] = cpu_baseline(data, csr, D, N, B, args.cpu_budget)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
