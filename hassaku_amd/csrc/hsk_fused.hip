@@ -9,6 +9,7 @@
 //   finish   loss reduction, global bias
 //
 // Reference semantics: one iteration of the loop at train/trainer.py:128-148 of the reference.
+#include <hip/hip_ext.h>
 #include "hsk_sampler.h"
 #include "hsk_sort.h"
 #include "hsk_step_kernels.h"
@@ -287,7 +288,7 @@ extern "C" void hsk_aux_destroy(void* a_) {
 extern "C" void* hsk_aux_create(void) {
   hsk_aux* a = new hsk_aux();
   bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreate(&a->ev_fork) == hipSuccess;   // a kernel stop event: must be able to take a timestamp
   ok = ok && hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     hsk_set_error("hsk_aux_create: could not create the side stream / events");
@@ -433,15 +434,25 @@ static int hsk_discard_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, hipStr
 static bool hsk_pf_early(int64_t B) { return B < 2048; }
 #define HSK_PREFETCH_MIN_ENTRIES 4096
 
-static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set, hipStream_t stream) {
+// true: this step will fork a prefetch (hint present and worth it)
+static bool hsk_prefetch_wanted(const hsk_bprmf_state* st) {
   hsk_aux* aux = (hsk_aux*)st->aux;
-  if (!aux || !aux->hint_valid) return HSK_OK;
+  if (!aux || !aux->hint_valid) return false;
   if (aux->hint_batch * (aux->hint_nneg + 1) < HSK_PREFETCH_MIN_ENTRIES) {
     aux->hint_valid = false;  // a few hundred entries: the fork/join events cost more than the five tiny kernels
-    return HSK_OK;
+    return false;
   }
+  return true;
+}
+
+// fork_recorded: ev_fork already rides on the forward kernel's completion signal (hipExtLaunchKernelGGL stop event),
+// which saves the separate barrier packet a hipEventRecord would put between the forward and the item pass
+static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set, hipStream_t stream,
+                               bool fork_recorded = false) {
+  hsk_aux* aux = (hsk_aux*)st->aux;
+  if (!hsk_prefetch_wanted(st)) return HSK_OK;
   const hsk_ws wn = hsk_select(w_all, set ^ 1);
-  HSK_HIP(hipEventRecord(aux->ev_fork, stream));
+  if (!fork_recorded) HSK_HIP(hipEventRecord(aux->ev_fork, stream));
   HSK_HIP(hipStreamWaitEvent(aux->side, aux->ev_fork, 0));
   int prc = hsk_launch_prep_sample(st, wn, aux->hint_order, aux->hint_start, aux->hint_batch, aux->hint_nneg,
                                    (uint64_t)st->step, aux->side);
@@ -479,6 +490,9 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     int prc = hsk_launch_prefetch(st, w_all, set, stream);
     if (prc) return prc;
   }
+  // late fork: the fork event is the forward kernel's own completion signal
+  const bool late_fork = !hsk_pf_early(B) && hsk_prefetch_wanted(st);
+  hipEvent_t fork_ev = late_fork ? aux->ev_fork : nullptr;
 
   int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
     constexpr int V = decltype(v_)::value;
@@ -499,10 +513,14 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       }
 #undef HSK_CATCH_UP
     }
-#define HSK_LAUNCH_FWD(LK)                                                                                         \
-  HSK_STAGE(HSK_STAGE_FWD, (k_fwd_ugrad<V, NCH, FULL, R, LK><<<(unsigned)hsk_ceil_div(B, 4), 256, 0, stream>>>(         \
-                               st->user_emb, st->item_emb, st->item_bias, w.u32, w.it32, (int)B, (int)K, D, inv_bn, \
-                               (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b)))
+#define HSK_LAUNCH_FWD(LK)                                                                                          \
+  HSK_STAGE(HSK_STAGE_FWD, (hipExtLaunchKernelGGL((k_fwd_ugrad<V, NCH, FULL, R, LK>), dim3((unsigned)hsk_ceil_div(B, 4)), \
+                                                  dim3(256), 0, stream, nullptr, fork_ev, 0,                         \
+                                                  (const float*)st->user_emb, (const float*)st->item_emb,            \
+                                                  (const float*)st->item_bias, (const int*)w.u32,                    \
+                                                  (const int*)w.it32, (int)B, (int)K, D, inv_bn,                     \
+                                                  (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b,                 \
+                                                  (const int*)nullptr)))
     if (st->loss_kind == HSK_LOSS_BCE) {
       HSK_LAUNCH_FWD(HSK_LOSS_BCE);
     } else if (st->loss_kind == HSK_LOSS_SSM) {
@@ -516,8 +534,8 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
 
-  if (!hsk_pf_early(B)) {
-    int prc = hsk_launch_prefetch(st, w_all, set, stream);
+  if (late_fork) {
+    int prc = hsk_launch_prefetch(st, w_all, set, stream, true);
     if (prc) return prc;
   }
 
