@@ -380,11 +380,33 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
   const int b = blockIdx.x;
   const int row = u32[b];
   if (row < 0) return;  // empty exchange slot (row-sharded mode)
-  if (owner[row] != b) return;
+  // row loads issued together with the owner / last_step lookups; thrown away by non-owners and current rows
+  float* prow = Uw + (long long)row * D;
+  float* mrow = mU + (long long)row * D;
+  float* vrow = vU + (long long)row * D;
+  const int d0 = threadIdx.x * VV;
+  hsk_vec<VV> p0 = hsk_zero<VV>(), m0 = hsk_zero<VV>(), v0 = hsk_zero<VV>();
+  if (d0 < D) {
+    p0 = hsk_ldg<VV>(prow + d0);
+    m0 = hsk_ldg<VV>(mrow + d0);
+    v0 = hsk_ldg<VV>(vrow + d0);
+  }
+  const int own = owner[row];
   const int done = last_step[row];
-  if (done >= step - 1) return;
-  hsk_row_replay_wg<VV, GEN>(Uw + (long long)row * D, mU + (long long)row * D, vU + (long long)row * D, D, done,
-                             step - 1, c, tab, tab_len);
+  if (own != b || done >= step - 1) return;
+  if (d0 < D) {   // first pass of the replay on the preloaded elements
+    for (int t = done + 1; t <= step - 1; ++t) {
+      const hsk_adamw_consts ct = hsk_consts_at(c, tab, tab_len, t);
+#pragma unroll
+      for (int q = 0; q < VV; ++q) hsk_adamw_update<GEN>(p0.v[q], m0.v[q], v0.v[q], 0.f, ct);
+    }
+    hsk_stg<VV>(prow + d0, p0);
+    hsk_stg<VV>(mrow + d0, m0);
+    hsk_stg<VV>(vrow + d0, v0);
+  }
+  if (D > 256 * VV)   // rows longer than one pass of the workgroup
+    hsk_row_replay_wg<VV, GEN>(prow + 256 * VV, mrow + 256 * VV, vrow + 256 * VV, D - 256 * VV, done, step - 1, c, tab,
+                               tab_len);
   __syncthreads();  // every thread has read last_step[row]
   if (threadIdx.x == 0) {
     if (Ub) {
@@ -459,12 +481,9 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
   if (b >= B) return;
   const int row = hsk_uniform_i(u32[b]);
   if (row < 0) return;  // empty exchange slot (row-sharded mode)
-  if (hsk_uniform_i(owner[row]) != b) return;
   using Row = hsk_row<V, NCH>;
-  const int n = hsk_uniform_i(cnt[row]);
-  Row g;
-  float dummy = 0.f;
-  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, dUb, u32, B, D, lane);
+  // the row loads are issued together with the owner / count lookups (one memory latency instead of two); a
+  // duplicate entry (not the owner) throws them away -- ~1 % of the entries at the BASELINE shapes
   float* prow = Uw + (long long)row * D;
   float* mrow = mU + (long long)row * D;
   float* vrow = vU + (long long)row * D;
@@ -472,6 +491,12 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
   hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
   hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
   hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  const int own = hsk_uniform_i(owner[row]);
+  const int n = hsk_uniform_i(cnt[row]);
+  if (own != b) return;
+  Row g;
+  float dummy = 0.f;
+  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, dUb, u32, B, D, lane);
 #pragma unroll
   for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
