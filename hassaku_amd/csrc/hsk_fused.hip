@@ -41,6 +41,7 @@ struct hsk_ws {
   float* dUb;
   double* loss_b;
   float2* adam_tab;
+  int *dupcnt, *duplist;   // per owner entry: how many / which further entries name the same user
   // second set of the per-batch buffers: the next batch is sampled and sorted into it while this one trains
   int *u32_b, *it32_b, *perm_b, *hist_b, *btot_b, *bstart_b, *offsets_b, *owner_b, *cnt_b;
   int2* perm1_b;
@@ -91,6 +92,8 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.dUb = (float*)take(max_batch * dim * 4);
   w.loss_b = (double*)take(max_batch * 8);
   w.adam_tab = (float2*)take((HSK_ADAM_TAB_LEN + 1) * sizeof(float2));
+  w.dupcnt = (int*)take(max_batch * 4);
+  w.duplist = (int*)take(max_batch * HSK_DUP_MAX * 4);
   w.u32_b = (int*)take(max_batch * 4);
   w.it32_b = (int*)take(ent * 4);
   w.perm1_b = (int2*)take(ent * 8);
@@ -164,6 +167,7 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   HSK_HIP(hipMemsetAsync(w.cnt, 0, st->n_users * 4, stream));
   HSK_HIP(hipMemsetAsync(w.cnt_b, 0, st->n_users * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.dupcnt, 0, st->max_batch * 4, stream));
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner, st->n_users, HSK_OWNER_NONE);
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner_b, st->n_users, HSK_OWNER_NONE);
   HSK_LAUNCH_CHECK();
@@ -505,7 +509,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<VV, GEN><<<(unsigned)B, 256, 0, stream>>>(                            \
                                 st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,      \
                                 st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,         \
-                                w.adam_tab, HSK_ADAM_TAB_LEN)))
+                                w.adam_tab, HSK_ADAM_TAB_LEN, w.dupcnt, w.duplist)))
       if (D % 2 == 0) {
         if (gen) HSK_CATCH_UP(2, true); else HSK_CATCH_UP(2, false);
       } else {
@@ -554,7 +558,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, GEN><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>( \
                                 st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,        \
                                 st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,               \
-                                (int)st->step, c, fin)))
+                                (int)st->step, c, fin, w.dupcnt, w.duplist)))
       if (gen) HSK_USER_LAZY(true); else HSK_USER_LAZY(false);
 #undef HSK_USER_LAZY
     } else {

@@ -238,11 +238,34 @@ __global__ __launch_bounds__(256) void k_item_update(const float* __restrict__ U
 //     MODE 0: dense AdamW sweep over all rows (one wave per table row)
 //     MODE 1: dense gradient output (compat backward)
 // =============================================================================================
+#define HSK_DUP_MAX 8   // duplicate entries of one user the catch-up kernel lists for the owner (more: batch scan)
+
 template <int V, int NCH, bool FULL>
 __device__ __forceinline__ void hsk_user_grad(hsk_row<V, NCH>& acc, float& gbias_unused, int row, int b0, int c,
                                               const float* __restrict__ dUb, const int* __restrict__ u32, int B,
-                                              int D, int lane) {
+                                              int D, int lane, int* __restrict__ dupcnt = nullptr,
+                                              const int* __restrict__ duplist = nullptr) {
   hsk_row_load<V, NCH, FULL>(acc, dUb + (long long)b0 * D, lane, D);
+  if (c > 1 && dupcnt) {
+    // the non-owner entries registered themselves with the owner (k_user_catch_up), in arrival order: sort the few
+    // of them so that the gradient rows are summed in ascending b, whatever the arrival order was
+    const int nd = hsk_uniform_i(dupcnt[b0]);
+    if (lane == 0) dupcnt[b0] = 0;
+    if (nd == c - 1 && nd <= HSK_DUP_MAX) {
+      const int mine = (lane < nd) ? duplist[b0 * HSK_DUP_MAX + lane] : 0x7fffffff;
+      int rank = 0;
+#pragma unroll
+      for (int k = 0; k < HSK_DUP_MAX; ++k) rank += (k < nd && hsk_readlane_i(mine, k) < mine) ? 1 : 0;
+      for (int r = 0; r < nd; ++r) {
+        const unsigned long long m = __ballot(lane < nd && rank == r);
+        const int bb = hsk_readlane_i(mine, __builtin_ctzll(m));
+        hsk_row<V, NCH> t;
+        hsk_row_load<V, NCH, FULL>(t, dUb + (long long)bb * D, lane, D);
+        hsk_row_add(acc, t);
+      }
+      return;
+    }
+  }
   if (c > 1) {
     // duplicates of this user further down the batch, in ascending b; the id loads of 8 chunks (512 entries) are
     // issued together so the scan costs a handful of memory latencies, not one per chunk
@@ -376,7 +399,8 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
                                                        const int* __restrict__ u32, const int* __restrict__ owner,
                                                        int* __restrict__ last_step, int B, int D, int step,
                                                        hsk_adamw_consts c, const float2* __restrict__ tab,
-                                                       int tab_len) {
+                                                       int tab_len, int* __restrict__ dupcnt = nullptr,
+                                                       int* __restrict__ duplist = nullptr) {
   const int b = blockIdx.x;
   const int row = u32[b];
   if (row < 0) return;  // empty exchange slot (row-sharded mode)
@@ -393,7 +417,15 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
   }
   const int own = owner[row];
   const int done = last_step[row];
-  if (own != b || done >= step - 1) return;
+  if (own != b) {
+    // a further entry of a user somebody else owns: tell the owner, who sums the gradient rows after the forward
+    if (dupcnt && threadIdx.x == 0 && own >= 0 && own < B) {
+      const int slot = atomicAdd(&dupcnt[own], 1);
+      if (slot < HSK_DUP_MAX) duplist[own * HSK_DUP_MAX + slot] = b;
+    }
+    return;
+  }
+  if (done >= step - 1) return;
   if (d0 < D) {   // first pass of the replay on the preloaded elements
     for (int t = done + 1; t <= step - 1; ++t) {
       const hsk_adamw_consts ct = hsk_consts_at(c, tab, tab_len, t);
@@ -470,7 +502,9 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
                                                           int* __restrict__ last_step, int B, int D, int step,
                                                           hsk_adamw_consts c,
                                                           hsk_finish_args fin = hsk_finish_args{nullptr, 0, 0.0, nullptr,
-                                                                                                nullptr, nullptr, nullptr}) {
+                                                                                                nullptr, nullptr, nullptr},
+                                                          int* __restrict__ dupcnt = nullptr,
+                                                          const int* __restrict__ duplist = nullptr) {
   if (fin.loss_b && blockIdx.x == (unsigned)((B + 3) / 4)) {
     hsk_finish_block(fin, c);
     return;
@@ -496,7 +530,7 @@ __global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw
   if (own != b) return;
   Row g;
   float dummy = 0.f;
-  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, dUb, u32, B, D, lane);
+  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, dUb, u32, B, D, lane, dupcnt, duplist);
 #pragma unroll
   for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
