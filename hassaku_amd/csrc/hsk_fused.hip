@@ -291,7 +291,14 @@ extern "C" void hsk_aux_destroy(void* a_) {
 
 extern "C" void* hsk_aux_create(void) {
   hsk_aux* a = new hsk_aux();
-  bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess;
+  // Priority of the side stream (measured at the ml10m shape, us/step): lowest 242 (the side chain starves behind
+  // the item pass and the next step waits for it), default 224, highest 222: its kernels are short and
+  // latency-bound, letting them through costs the item pass less than a late join costs the step.
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  const char* pe = getenv("HSK_SIDE_PRIO");
+  const int prio = pe ? atoi(pe) : prio_hi;
+  bool ok = hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, prio) == hipSuccess;
   ok = ok && hipEventCreate(&a->ev_fork) == hipSuccess;   // a kernel stop event: must be able to take a timestamp
   ok = ok && hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
