@@ -189,6 +189,27 @@ __device__ __forceinline__ void hsk_adamw_update(float& p, float& m, float& v, f
 #endif
 }
 
+
+// The same update for g == 0 (the lazy replay): two operations fewer, bit-identical to hsk_adamw_update(..., 0.f, c)
+// (0 - m and -m differ only in the sign of a zero that fma(w1, ., m) absorbs; (1-b2)*0*0 + v*b2 == v*b2 for v >= 0).
+template <bool GEN = true>
+__device__ __forceinline__ void hsk_adamw_replay(float& p, float& m, float& v, const hsk_adamw_consts& c) {
+  if (GEN) {
+    hsk_adamw_update<true>(p, m, v, 0.f, c);
+    return;
+  }
+  p = p * c.decay;
+  m = fmaf(c.w1, -m, m);
+  v = v * c.beta2;
+#if HSK_ADAM_IEEE
+  float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p = p - c.step_size * (m / denom);
+#else
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), c.rbc2_sqrt, c.eps);
+  p = fmaf(-c.step_size * m, __builtin_amdgcn_rcpf(denom), p);
+#endif
+}
+
 #endif  // __HIPCC__
 
 #ifdef __cplusplus

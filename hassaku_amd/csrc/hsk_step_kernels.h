@@ -382,7 +382,7 @@ __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, floa
     for (int t = from + 1; t <= to; ++t) {
       const hsk_adamw_consts c = hsk_consts_at(base, tab, tab_len, t);
 #pragma unroll
-      for (int q = 0; q < VV; ++q) hsk_adamw_update<GEN>(p.v[q], m.v[q], v.v[q], 0.f, c);
+      for (int q = 0; q < VV; ++q) hsk_adamw_replay<GEN>(p.v[q], m.v[q], v.v[q], c);
     }
     hsk_stg<VV>(prow + d0, p);
     hsk_stg<VV>(mrow + d0, m);
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
     for (int t = done + 1; t <= step - 1; ++t) {
       const hsk_adamw_consts ct = hsk_consts_at(c, tab, tab_len, t);
 #pragma unroll
-      for (int q = 0; q < VV; ++q) hsk_adamw_update<GEN>(p0.v[q], m0.v[q], v0.v[q], 0.f, ct);
+      for (int q = 0; q < VV; ++q) hsk_adamw_replay<GEN>(p0.v[q], m0.v[q], v0.v[q], ct);
     }
     hsk_stg<VV>(prow + d0, p0);
     hsk_stg<VV>(mrow + d0, m0);
