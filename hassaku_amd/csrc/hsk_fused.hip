@@ -524,14 +524,24 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       }
 #undef HSK_CATCH_UP
     }
+    // The forward kernel is launched through hipExtLaunchKernelGGL, whose start / stop events are the dispatch's own
+    // timestamps: on a timed step they ARE the stage timing (kernel time as rocprofv3 reports it, no barrier packets
+    // around the launch); otherwise the stop event is the prefetch's fork event.
+    hipEvent_t fwd_beg = nullptr, fwd_end = fork_ev;
+    hsk_timing* tm = (hsk_timing*)st->timing;
+    const bool time_fwd = tm && st->timing_now && ((st->timing_mask >> HSK_STAGE_FWD) & 1);
+    if (time_fwd) {
+      fwd_beg = tm->get();
+      fwd_end = tm->get();
+      if (!fwd_beg || !fwd_end) return HSK_ERR_HIP;
+      tm->beg[HSK_STAGE_FWD].push_back(fwd_beg);
+      tm->end[HSK_STAGE_FWD].push_back(fwd_end);
+    }
 #define HSK_LAUNCH_FWD(LK)                                                                                          \
-  HSK_STAGE(HSK_STAGE_FWD, (hipExtLaunchKernelGGL((k_fwd_ugrad<V, NCH, FULL, R, LK>), dim3((unsigned)hsk_ceil_div(B, 4)), \
-                                                  dim3(256), 0, stream, nullptr, fork_ev, 0,                         \
-                                                  (const float*)st->user_emb, (const float*)st->item_emb,            \
-                                                  (const float*)st->item_bias, (const int*)w.u32,                    \
-                                                  (const int*)w.it32, (int)B, (int)K, D, inv_bn,                     \
-                                                  (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b,                 \
-                                                  (const int*)nullptr)))
+  hipExtLaunchKernelGGL((k_fwd_ugrad<V, NCH, FULL, R, LK>), dim3((unsigned)hsk_ceil_div(B, 4)), dim3(256), 0, stream,  \
+                        fwd_beg, fwd_end, 0, (const float*)st->user_emb, (const float*)st->item_emb,                \
+                        (const float*)st->item_bias, (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D,      \
+                        inv_bn, (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b, (const int*)nullptr)
     if (st->loss_kind == HSK_LOSS_BCE) {
       HSK_LAUNCH_FWD(HSK_LOSS_BCE);
     } else if (st->loss_kind == HSK_LOSS_SSM) {
@@ -546,7 +556,8 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   HSK_LAUNCH_CHECK();
 
   if (late_fork) {
-    int prc = hsk_launch_prefetch(st, w_all, set, stream, true);
+    const bool fork_on_kernel = !(st->timing && st->timing_now && ((st->timing_mask >> HSK_STAGE_FWD) & 1));
+    int prc = hsk_launch_prefetch(st, w_all, set, stream, fork_on_kernel);
     if (prc) return prc;
   }
 
