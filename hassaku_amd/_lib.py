@@ -52,7 +52,7 @@ class HskBprmfMp(ctypes.Structure):
         ('grads_send', c_void_p), ('grads_recv', c_void_p),
         ('g_item_emb', c_void_p), ('g_item_bias', c_void_p),
         ('slot_of_b', c_void_p),
-        ('cur_batch', c_int64), ('cur_cols', c_int64),
+        ('cur_batch', c_int64), ('cur_cols', c_int64), ('users_applied', c_int64),
     ]
 
 
@@ -85,9 +85,11 @@ SIGNATURES = {
     'hsk_aux_destroy': (None, [c_void_p]),
     'hsk_bprmf_hint_next': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
     'hsk_mp_prep': (c_int, [POINTER(HskBprmfMp), c_void_p, c_int64, c_int64, c_int64, c_void_p]),
-    'hsk_mp_serve': (c_int, [POINTER(HskBprmfMp), c_void_p]),
-    'hsk_mp_compute': (c_int, [POINTER(HskBprmfMp), c_void_p]),
-    'hsk_mp_apply': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_sort': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_forward': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_item_grad': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_apply_users': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_mp_apply_items': (c_int, [POINTER(HskBprmfMp), c_void_p]),
     'hsk_mp_flush': (c_int, [POINTER(HskBprmfMp), c_void_p]),
     'hsk_bprmf_flush': (c_int, [POINTER(HskBprmfState), c_void_p]),
     'hsk_bprmf_last_batch': (c_int, [POINTER(HskBprmfState), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -9,10 +9,13 @@ Replaces the reference's single-process nn.DataParallel (train/trainer.py:38-41)
   * the global batch of world*B positives is cut into contiguous slices, the sampler's RNG is keyed by the global
     batch position, so N GPUs compute the step one GPU would compute on the same world*B batch.
 
-Per step and rank: all_to_all 4*C*world B (requests), all_to_all 4*D*C*world B (user rows to the requesters),
-all_reduce 4*(D+1)*I B (item gradient), all_to_all 4*D*C*world B (user-row gradients back to the owners);
-C = per-pair slot capacity ~ B/world + 6 sigma.  xGMI is a point-to-point mesh: the all_to_alls use every link at
-once; the all_reduce is the bandwidth term (21.9 MB at I=10 677, D=512).
+Per step and rank: all_to_all 4*D*C*world B (user rows to the requesters; the requests themselves are recomputed
+by the owner, every rank knows every slice of the global batch), all_to_all 4*D*C*world B (user-row gradients back
+to the owners), all_reduce 4*(D+1)*I B (item gradient); C = per-pair slot capacity ~ B/world + 6 sigma.  Each
+collective is issued asynchronously and has independent kernels running under it: the item sort under the row
+exchange, the item-gradient pass under the gradient-row exchange, the user update under the all_reduce.  xGMI is a
+point-to-point mesh: the all_to_alls use every link at once; the all_reduce is the bandwidth term (21.9 MB at
+I=10 677, D=512).
 
 Evaluation shards the USERS the same way (each rank scores the users it owns against the replicated item
 table; per-group metric sums and counts are all-reduced), which needs no table exchange at all.
@@ -29,9 +32,19 @@ from hassaku_amd._lib import HskBprmfMp
 from hassaku_amd.hip_ops import ADAM_BETA1, ADAM_BETA2, ADAM_EPS, _chk, _p, _stream
 
 
+class _Done:
+    """Handle of a collective that has already completed (host-staged backends)."""
+
+    def wait(self):
+        return True
+
+
 class Comm:
-    """The four collectives the sharded step needs, on device tensors.  With backend nccl (= RCCL on ROCm) they
-    run on the GPU directly; any other backend (gloo in the tests) is staged through host memory."""
+    """The collectives the sharded step needs, on device tensors.  With backend nccl (= RCCL on ROCm) they run on
+    the GPU directly -- `async_op=True` returns the torch Work handle, the collective then runs on RCCL's own stream
+    behind everything already queued on the current stream, and `handle.wait()` makes the current stream wait for
+    it: kernels launched in between overlap the exchange.  Any other backend (gloo in the tests) is staged through
+    host memory, synchronously; the handle is then already complete."""
 
     def __init__(self, group=None):
         if not dist.is_initialized():
@@ -41,25 +54,30 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.native = dist.get_backend(group) == 'nccl'
 
-    def all_reduce(self, t: torch.Tensor):
-        if self.native or not t.is_cuda:
+    def all_reduce(self, t: torch.Tensor, async_op: bool = False):
+        if self.native:
+            work = dist.all_reduce(t, group=self.group, async_op=async_op)
+            return work if async_op else None
+        if not t.is_cuda:
             dist.all_reduce(t, group=self.group)
         else:
             h = t.cpu()
             dist.all_reduce(h, group=self.group)
             t.copy_(h)
+        return _Done() if async_op else None
 
-    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         """Equal splits along dim 0: out[j*n:(j+1)*n] on rank i = inp[i*n:(i+1)*n] of rank j."""
         if self.native:
-            dist.all_to_all_single(out, inp, group=self.group)
-            return
+            work = dist.all_to_all_single(out, inp, group=self.group, async_op=async_op)
+            return work if async_op else None
         h = inp.cpu()
         parts = [torch.empty_like(h) for _ in range(self.world)]
         dist.all_gather(parts, h, group=self.group)
         n = h.shape[0] // self.world
         res = torch.cat([p[self.rank * n:(self.rank + 1) * n] for p in parts], dim=0)
         out.copy_(res)
+        return _Done() if async_op else None
 
     def all_gather(self, inp: torch.Tensor):
         """-> list of world tensors shaped like inp."""
@@ -191,7 +209,7 @@ class ShardedBprMf:
         mp.g_item_emb = _p(self.g_item)
         mp.g_item_bias = (self.g_item.data_ptr() + 4 * I * D) if item_bias is not None else None
         mp.slot_of_b = _p(self.slot_of_b)
-        mp.cur_batch = mp.cur_cols = 0
+        mp.cur_batch = mp.cur_cols = mp.users_applied = 0
         self.mp = mp
         _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(mp.base), _stream()), 'hsk_bprmf_init_workspace')
 
@@ -208,14 +226,20 @@ class ShardedBprMf:
             if start_global + comm.world * nb > order.numel():
                 raise ValueError('order too short for the global batch')
         s = _stream()
-        _lib.check(lib.hsk_mp_prep(ctypes.byref(mp), _p(order), start_global, nb, self.n_neg, s), 'hsk_mp_prep')
-        comm.all_to_all(self.req_recv, self.req_send)
-        _lib.check(lib.hsk_mp_serve(ctypes.byref(mp), s), 'hsk_mp_serve')
-        comm.all_to_all(self.rows_recv, self.rows_send)
-        _lib.check(lib.hsk_mp_compute(ctypes.byref(mp), s), 'hsk_mp_compute')
-        comm.all_reduce(self.g_item)
-        comm.all_to_all(self.grads_recv, self.grads_send)
-        _lib.check(lib.hsk_mp_apply(ctypes.byref(mp), s), 'hsk_mp_apply')
+        ref = ctypes.byref(mp)
+        # sample + route (own requests and, recomputed locally, the incoming ones) + owner catch-up + pack
+        _lib.check(lib.hsk_mp_prep(ref, _p(order), start_global, nb, self.n_neg, s), 'hsk_mp_prep')
+        rows = comm.all_to_all(self.rows_recv, self.rows_send, async_op=True)
+        _lib.check(lib.hsk_mp_sort(ref, s), 'hsk_mp_sort')                    # under the row exchange
+        rows.wait()
+        _lib.check(lib.hsk_mp_forward(ref, s), 'hsk_mp_forward')
+        grads = comm.all_to_all(self.grads_recv, self.grads_send, async_op=True)
+        _lib.check(lib.hsk_mp_item_grad(ref, s), 'hsk_mp_item_grad')          # under the gradient-row exchange
+        items = comm.all_reduce(self.g_item, async_op=True)
+        grads.wait()
+        _lib.check(lib.hsk_mp_apply_users(ref, s), 'hsk_mp_apply_users')      # under the item-gradient all_reduce
+        items.wait()
+        _lib.check(lib.hsk_mp_apply_items(ref, s), 'hsk_mp_apply_items')
 
     # -- per-stage device timing (same recorder as the single-GPU state; 'fwd' and 'item' are bracketed) -----
     def enable_timing(self, stages=('fwd',), every=1):

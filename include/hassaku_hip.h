@@ -282,17 +282,22 @@ int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_col
  * [r*batch, (r+1)*batch).  The library runs the compute phases; the caller runs the collectives between
  * them (RCCL through torch.distributed, or anything else that moves the buffers below):
  *
- *   hsk_mp_prep      sample the local slice (RNG keyed by the GLOBAL batch position), sort its entries by item,
- *                    route each positive's user to its owner: req_send[dst*C + s] = local row at dst, or -1
- *     all_to_all(req_send -> req_recv)                                    4*world*C bytes per rank
- *   hsk_mp_serve     owner: replay missed zero-gradient steps of the requested rows, pack them into rows_send
+ *   hsk_mp_prep        sample the local slice (RNG keyed by the GLOBAL batch position); route each positive's user
+ *                      to its owner (slot_of_b; req_send[dst*C + s] = local row at dst, or -1).  The requests this
+ *                      rank will RECEIVE need no exchange: every rank knows every slice of the global batch (same
+ *                      COO, same epoch order), so req_recv is recomputed locally.  Owner: replay the missed
+ *                      zero-gradient steps of the requested rows, pack them into rows_send
  *     all_to_all(rows_send -> rows_recv)                                  4*D*world*C bytes per rank
- *   hsk_mp_compute   forward + BPR + user-row grads (-> grads_send) + dense partial item gradient
- *     all_reduce(g_item_emb, g_item_bias; sum)                            4*(D+1)*I bytes
+ *   hsk_mp_sort        item sort of the local entries -- independent of the exchange, so it overlaps it
+ *   hsk_mp_forward     forward + loss + user-row grads (-> grads_send)              [needs rows_recv]
  *     all_to_all(grads_send -> grads_recv)                                4*D*world*C bytes per rank
- *   hsk_mp_apply     AdamW on the (replicated) item table with the reduced gradient; owner: AdamW on the
- *                    requested user rows (duplicates summed in slot order); loss_out[0] = this rank's share of
- *                    the global mean loss (sum over ranks = loss), loss_out[1] accumulates it
+ *   hsk_mp_item_grad   dense partial item gradient (-> g_item_emb, g_item_bias) -- overlaps that exchange
+ *     all_reduce(g_item_emb, g_item_bias; sum)                            4*(D+1)*I bytes
+ *   hsk_mp_apply_users owner: AdamW on the requested user rows (duplicates summed in slot order)  [needs grads_recv];
+ *                      loss_out[0] = this rank's share of the global mean loss (sum over ranks = loss),
+ *                      loss_out[1] accumulates it -- overlaps the all_reduce
+ *   hsk_mp_apply_items AdamW on the (replicated) item table with the reduced gradient  [needs the all_reduce];
+ *                      closes the step.  Must follow hsk_mp_apply_users.
  *
  * Result = the single-GPU step on the global batch (same samples; fp32 summation order of the item gradient
  * differs).  C = capacity (slots per rank pair); HSK_STATUS_ROUTE_OVERFLOW is raised if a pair needs more.
@@ -314,13 +319,16 @@ typedef struct hsk_bprmf_mp {
   float* g_item_bias;         /* [I] (NULL without item bias) */
   int32_t* slot_of_b;         /* [batch] */
   int64_t cur_batch, cur_cols; /* library scratch: shape of the step in flight */
+  int64_t users_applied;       /* library scratch: hsk_mp_apply_users of the step in flight has run */
 } hsk_bprmf_mp;
 
 int hsk_mp_prep(hsk_bprmf_mp* mp, const int64_t* order, int64_t start_global, int64_t batch, int64_t n_neg,
                 hsk_stream_t stream);
-int hsk_mp_serve(hsk_bprmf_mp* mp, hsk_stream_t stream);
-int hsk_mp_compute(hsk_bprmf_mp* mp, hsk_stream_t stream);
-int hsk_mp_apply(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int hsk_mp_sort(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int hsk_mp_forward(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int hsk_mp_item_grad(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int hsk_mp_apply_users(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int hsk_mp_apply_items(hsk_bprmf_mp* mp, hsk_stream_t stream);
 /* bring every local user row up to date (before evaluation / gathering the table) */
 int hsk_mp_flush(hsk_bprmf_mp* mp, hsk_stream_t stream);
 

@@ -75,9 +75,13 @@ def _cpu_protocol_worker(rank, world, port, out_dir):
         gi = rng.randint(0, I, size=(world * B, N + 1)).astype(np.int64)
         lu, li = gu[rank * B:(rank + 1) * B], gi[rank * B:(rank + 1) * B]
         req, slot_of_b = _route_host(lu, world, C)
-        req_recv = torch.empty(world * C, dtype=torch.int32)
-        comm.all_to_all(req_recv, torch.from_numpy(req))
-        req_recv = req_recv.numpy()
+        # the owner recomputes the requests it will receive from the global batch every rank knows ...
+        req_recv = np.concatenate([_route_host(gu[s * B:(s + 1) * B], world, C)[0][rank * C:(rank + 1) * C]
+                                   for s in range(world)])
+        # ... which is exactly what exchanging them would deliver
+        exchanged = torch.empty(world * C, dtype=torch.int32)
+        comm.all_to_all(exchanged, torch.from_numpy(req))
+        assert np.array_equal(exchanged.numpy(), req_recv)
         rows_send = np.zeros((world * C, D), np.float32)
         ok = req_recv >= 0
         rows_send[ok] = Uloc[req_recv[ok]]
