@@ -528,3 +528,46 @@ def test_full_size_properties_cfg3(ops):
     st2 = ops.BprMfFusedState(Z['user_emb'], Z['item_emb'], None, lr=1e-3, wd=0.0, max_batch=B, max_cols=N + 1)
     st2.step(torch.randint(0, 1000, (B,), device='cuda'), i)
     assert abs(st2.last_loss() - np.log(2.0)) < 1e-7  # softplus evaluated in fp32
+
+
+def test_full_size_fused_step_equals_unfused_operator_chain(ops, oracle):
+    """BASELINE configs[2] in full (ml10m-shaped synthetic interactions, D=512, N=100, B=4096): one device-sampled fused
+    step -- sampler, item sort, forward, item pass, lazy user update -- against the un-fused HIP operators
+    (hsk_mf_scores -> hsk_bpr_loss_grad -> hsk_mf_backward -> hsk_adamw_dense), which the small-shape tests pin to the
+    reference's golden vectors.  Plus the sampler's invariants on the whole 4096 x 100 draw."""
+    from hassaku_amd.data import synthetic
+    from hassaku_amd.data.csr import UserItemCsr
+    data = synthetic.generate_named('ml10m', seed=0)
+    U, I, D, B, N = data.n_users, data.n_items, 512, 4096, 100
+    csr = UserItemCsr.from_pairs(data.train[:, 0], data.train[:, 1], U, I)
+    indptr, indices = csr.to_device('cuda')
+    torch.manual_seed(64)
+    P = {'user_emb': torch.empty((U, D), device='cuda').normal_(std=0.05), 'item_emb': torch.empty((I, D), device='cuda').normal_(std=0.05),
+         'item_bias': torch.empty((I,), device='cuda').normal_(std=0.1)}
+    Q = {k: v.clone() for k, v in P.items()}
+    lr, wd = 3e-4, 4e-5
+    st = ops.BprMfFusedState(P['user_emb'], P['item_emb'], P['item_bias'], lr=lr, wd=wd, max_batch=B, max_cols=N + 1, seed=64,
+                             csr_indptr=indptr, csr_indices=indices,
+                             coo_user=torch.from_numpy(data.train[:, 0].astype(np.int32)).cuda(),
+                             coo_item=torch.from_numpy(data.train[:, 1].astype(np.int32)).cuda())
+    order = torch.randperm(data.train.shape[0], device='cuda')
+    st.step_sampled(order, 0, B, N)
+    st.flush()
+    st.check_status()
+    u, i = st.last_batch(B, N + 1)
+    sel = order[:B].cpu().numpy()
+    assert np.array_equal(u.cpu().numpy(), data.train[sel, 0]) and np.array_equal(i[:, 0].cpu().numpy(), data.train[sel, 1])
+    ptr_h, idx_h = csr.indptr, csr.indices
+    assert oracle.count_bad_negatives(np.asarray(ptr_h), np.asarray(idx_h), I, u.cpu().numpy(), i[:, 1:].cpu().numpy()) == 0
+    # the same step from the un-fused operators
+    logits = ops.mf_scores(Q['user_emb'], Q['item_emb'], Q['item_bias'], None, None, u, i)
+    loss, g = ops.bpr_loss_grad(logits)
+    assert abs(st.last_loss() - loss.item()) <= 1e-6 * loss.item()
+    assert float(g.sum(dim=1).abs().max()) < 1e-9            # BPR: the gradient wrt a row of logits sums to zero
+    g_u, g_i, g_ib, _, _ = ops.mf_backward(Q['user_emb'], Q['item_emb'], u, i, g, True, False, False)
+    for name, grad in (('user_emb', g_u), ('item_emb', g_i), ('item_bias', g_ib)):
+        m, v = torch.zeros_like(Q[name]), torch.zeros_like(Q[name])
+        ops.adamw_dense(Q[name], grad, m, v, lr, wd, 1)
+        assert_adam_param_close(P[name].cpu().numpy(), Q[name].cpu().numpy(), name)
+        assert max_norm_err(st.m[name].cpu().numpy(), m.cpu().numpy()) < 1e-5, name
+        assert max_norm_err(st.v[name].cpu().numpy(), v.cpu().numpy()) < 1e-5, name
