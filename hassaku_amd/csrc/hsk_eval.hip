@@ -68,44 +68,55 @@ __global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Uw
   const int half = lane >> 5;
   const int l32 = lane & 31;
 
-  for (int k0 = 0; k0 < D; k0 += GEMM_BK) {
+  // Register-staged double buffering: the global loads of k-tile t+1 are issued before the MFMAs of tile t and
+  // land in registers while the matrix cores work; they go to LDS after the tile's last read.  (Loading straight
+  // into LDS inside the loop left the memory latency of every tile exposed: 78 TFLOP/s; staged: see DESIGN.md.)
+  float4 ra[4], rb[4];
+  auto load_tile = [&](int k0) {
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = srow + pass * 32;
-      // A: user rows (gathered through urow)
-      {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + r < n_rows) {
-          const float* src = Uw + (long long)urow[r] * D + k0 + scol;
-          if (VEC4) {
-            if (k0 + scol < D) v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (k0 + scol + 0 < D) v.x = src[0];
-            if (k0 + scol + 1 < D) v.y = src[1];
-            if (k0 + scol + 2 < D) v.z = src[2];
-            if (k0 + scol + 3 < D) v.w = src[3];
-          }
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < n_rows) {   // A: user rows (gathered through urow)
+        const float* src = Uw + (long long)urow[r] * D + k0 + scol;
+        if (VEC4) {
+          if (k0 + scol < D) va = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k0 + scol + 0 < D) va.x = src[0];
+          if (k0 + scol + 1 < D) va.y = src[1];
+          if (k0 + scol + 2 < D) va.z = src[2];
+          if (k0 + scol + 3 < D) va.w = src[3];
         }
-        *reinterpret_cast<float4*>(&As[r * GEMM_LDS_STRIDE + scol]) = v;
       }
-      // B: item rows of the shard
-      {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 + r < item_count) {
-          const float* src = Iw + (item_begin + n0 + r) * (long long)D + k0 + scol;
-          if (VEC4) {
-            if (k0 + scol < D) v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (k0 + scol + 0 < D) v.x = src[0];
-            if (k0 + scol + 1 < D) v.y = src[1];
-            if (k0 + scol + 2 < D) v.z = src[2];
-            if (k0 + scol + 3 < D) v.w = src[3];
-          }
+      if (n0 + r < item_count) {   // B: item rows of the shard
+        const float* src = Iw + (item_begin + n0 + r) * (long long)D + k0 + scol;
+        if (VEC4) {
+          if (k0 + scol < D) vb = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k0 + scol + 0 < D) vb.x = src[0];
+          if (k0 + scol + 1 < D) vb.y = src[1];
+          if (k0 + scol + 2 < D) vb.z = src[2];
+          if (k0 + scol + 3 < D) vb.w = src[3];
         }
-        *reinterpret_cast<float4*>(&Bs[r * GEMM_LDS_STRIDE + scol]) = v;
       }
+      ra[pass] = va;
+      rb[pass] = vb;
     }
-    __syncthreads();
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = srow + pass * 32;
+      *reinterpret_cast<float4*>(&As[r * GEMM_LDS_STRIDE + scol]) = ra[pass];
+      *reinterpret_cast<float4*>(&Bs[r * GEMM_LDS_STRIDE + scol]) = rb[pass];
+    }
+  };
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int k0 = 0; k0 < D; k0 += GEMM_BK) {
+    const bool has_next = k0 + GEMM_BK < D;
+    if (has_next) load_tile(k0 + GEMM_BK);
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -127,6 +138,10 @@ __global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Uw
         }
     }
     __syncthreads();
+    if (has_next) {
+      store_tile();
+      __syncthreads();
+    }
   }
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -184,6 +199,7 @@ __device__ __forceinline__ float hsk_key2f(uint32_t k) {
 }
 
 #define TOPK_MAX 1024
+#define TOPK_CAND_MAX 2048   // LDS candidates of the two-pass fast path (>= TOPK_MAX)
 
 // sorts n (power of two, <= TOPK_MAX... up to 4096) composite keys in LDS descending
 __device__ void hsk_bitonic_desc(unsigned long long* s, int n) {
@@ -210,12 +226,75 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, 
                                                    int kpad, long long idx_offset, float* __restrict__ out_vals,
                                                    IdxOut* __restrict__ out_idx) {
   __shared__ unsigned int hist[256];
-  __shared__ unsigned long long cand[TOPK_MAX];
+  __shared__ unsigned long long cand[TOPK_CAND_MAX];
   __shared__ unsigned int sh_prefix, sh_need, sh_ngt, sh_neq, sh_taken;
   __shared__ unsigned int wave_cnt[4];
+  __shared__ unsigned int hist12[4096];
+  __shared__ unsigned int part12[256];
 
   const int tid = threadIdx.x;
   const float* __restrict__ row = X + (long long)blockIdx.x * ld;
+
+  // Fast path, two reads of the row instead of five: a 12-bit histogram (sign, exponent, 3 mantissa bits) finds the
+  // bin b1 that holds the k-th largest key; everything in a higher bin is certainly in the top k, everything in b1
+  // may be.  If those candidates fit into LDS they are gathered in one more pass and sorted there (key descending,
+  // index ascending -- the same tie rule as below).  Rows with more candidates than that (long runs of equal scores,
+  // e.g. -inf) take the general 4 x 8-bit radix select below.
+  if (cols >= 4096) {
+    for (int c = tid; c < 4096; c += 256) hist12[c] = 0;
+    __syncthreads();
+    for (int c = tid; c < cols; c += 256) atomicAdd(&hist12[hsk_f2key(row[c]) >> 20], 1u);
+    __syncthreads();
+    {
+      unsigned int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum += hist12[tid * 16 + j];
+      part12[tid] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int cum = 0;   // keys in bins above the current one
+      int g = 255;
+      for (; g > 0; --g) {
+        if (cum + part12[g] >= (unsigned)k) break;
+        cum += part12[g];
+      }
+      int bin = g * 16 + 15;
+      for (; bin > g * 16; --bin) {
+        if (cum + hist12[bin] >= (unsigned)k) break;
+        cum += hist12[bin];
+      }
+      sh_prefix = (unsigned)bin;         // b1
+      sh_ngt = cum;                      // keys in higher bins (< k)
+      sh_neq = hist12[bin];              // keys in b1
+      sh_taken = 0;
+    }
+    __syncthreads();
+    const unsigned int b1 = sh_prefix, n_cand = sh_ngt + sh_neq;
+    if (n_cand <= TOPK_CAND_MAX) {
+      int npad = 1;
+      while (npad < (int)n_cand) npad <<= 1;
+      if (npad < kpad) npad = kpad;
+      for (int c = tid; c < npad; c += 256) cand[c] = 0ull;   // pads sort last
+      __syncthreads();
+      for (int c = tid; c < cols; c += 256) {
+        const uint32_t key = hsk_f2key(row[c]);
+        if ((key >> 20) >= b1) {
+          const unsigned int slot = atomicAdd(&sh_taken, 1u);
+          cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)c);
+        }
+      }
+      __syncthreads();
+      hsk_bitonic_desc(cand, npad);
+      for (int c = tid; c < k; c += 256) {
+        const unsigned long long v = cand[c];
+        out_vals[(long long)blockIdx.x * k + c] = hsk_key2f((uint32_t)(v >> 32));
+        out_idx[(long long)blockIdx.x * k + c] = (IdxOut)((long long)(~(uint32_t)v) + idx_offset);
+      }
+      return;
+    }
+    __syncthreads();
+  }
 
   uint32_t prefix = 0, prefix_mask = 0;
   unsigned int need = (unsigned)k;  // how many still to take among keys matching the prefix

@@ -481,6 +481,26 @@ def test_topk_dense_ties_and_neg_inf(ops, oracle):
     assert idx.dtype == torch.int64
 
 
+def test_topk_wide_rows_fast_path_and_fallback(ops, oracle):
+    """cols >= 4096 takes the two-pass path (12-bit histogram, candidates sorted in LDS); rows whose candidate bin
+    overflows LDS (long runs of equal values) fall back to the 4 x 8-bit radix select.  Exact ids either way."""
+    g = torch.Generator(device='cuda').manual_seed(4)
+    C = 9000
+    x = torch.randn(8, C, device='cuda', generator=g)
+    x[1] = (x[1] * 2).round() / 2                         # ~1500 values per level: ties inside the candidate bin
+    x[2, :] = 0.25                                        # one value everywhere: > 2048 candidates -> fallback
+    x[3, :] = float('-inf'); x[3, ::97] = torch.randn(len(range(0, C, 97)), device='cuda', generator=g)   # 93 finite < k
+    x[4] = torch.randn(C, device='cuda', generator=g) * 1e-30       # denormal-range magnitudes
+    x[5, 4000:] = float('-inf')                           # the exclusion mask of a heavy user
+    x[6] = -x[0]
+    x[7] = torch.arange(C, device='cuda', dtype=torch.float32) % 50  # 180 copies of each level, k cuts through one
+    for k in (100, 5):
+        vals, idx = ops.topk_dense(x, k)
+        rv, ri = oracle.topk(x.cpu().numpy(), k)
+        assert np.array_equal(idx.cpu().numpy(), ri), k
+        assert np.array_equal(vals.cpu().numpy(), rv), k
+
+
 def test_rank_metrics_vs_reference_functions(ops):
     fx = load_golden('g5_metrics.npz')
     y = fx['y_true']
