@@ -14,6 +14,7 @@
 #include "hsk_sort.h"
 #include "hsk_step_kernels.h"
 #include "hsk_item_sliced.h"
+#include "hsk_fwd_small.h"
 #include <stdlib.h>
 
 #include <utility>
@@ -404,6 +405,21 @@ static int hsk_launch_prep_sample(const hsk_bprmf_state* st, const hsk_ws& w, co
 // item sort of the entries in w.it32 -> w.perm / w.offsets
 static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t total, hipStream_t stream) {
   const int I = (int)st->n_items;
+  if (total <= 1024 * 8) {
+    // one workgroup sorts the whole batch (see k_sort_small)
+    int nbits = 1;
+    while ((1ll << nbits) <= (long long)I) ++nbits;   // keys 0..I (I = padding) fit
+    HSK_STAGE(HSK_STAGE_SCATTER, {
+      if (total <= 1024 * 2)
+        k_sort_small<2><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets);
+      else if (total <= 1024 * 4)
+        k_sort_small<4><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets);
+      else
+        k_sort_small<8><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets);
+    });
+    HSK_LAUNCH_CHECK();
+    return HSK_OK;
+  }
   hsk_sort_plan plan;
   HSK_REQUIRE(hsk_make_sort_plan(I, total, &plan) == 0, HSK_ERR_UNSUPPORTED, "item sort: n_items too large");
   const size_t bucket_lds = (size_t)5 * plan.ipb * sizeof(int);
@@ -542,7 +558,19 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
                         fwd_beg, fwd_end, 0, (const float*)st->user_emb, (const float*)st->item_emb,                \
                         (const float*)st->item_bias, (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D,      \
                         inv_bn, (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b, (const int*)nullptr)
-    if (st->loss_kind == HSK_LOSS_BCE) {
+    // small batches: a workgroup per positive (hsk_fwd_small.h); the one-wave kernel would leave most SIMDs idle
+    // and walk each positive's rows as a chain of memory latencies
+#define HSK_LAUNCH_FWD_WG(LK)                                                                                       \
+  hipExtLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK>), dim3((unsigned)B), dim3(256),                          \
+                        (unsigned)(4 * (size_t)D * sizeof(float)), stream, fwd_beg, fwd_end, 0,                      \
+                        (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,        \
+                        (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b)
+    const bool wg_fwd = B <= 1024 && st->loss_kind != HSK_LOSS_SSM && K >= 9;
+    if (wg_fwd && st->loss_kind == HSK_LOSS_BCE) {
+      HSK_LAUNCH_FWD_WG(HSK_LOSS_BCE);
+    } else if (wg_fwd) {
+      HSK_LAUNCH_FWD_WG(HSK_LOSS_BPR);
+    } else if (st->loss_kind == HSK_LOSS_BCE) {
       HSK_LAUNCH_FWD(HSK_LOSS_BCE);
     } else if (st->loss_kind == HSK_LOSS_SSM) {
       HSK_LAUNCH_FWD(HSK_LOSS_SSM);
@@ -550,6 +578,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       HSK_LAUNCH_FWD(HSK_LOSS_BPR);
     }
 #undef HSK_LAUNCH_FWD
+#undef HSK_LAUNCH_FWD_WG
     return HSK_OK;
   });
   if (rc) return rc;

@@ -17,6 +17,9 @@
 // latency-bound, not bandwidth-bound (the whole entry list is 1.6 MB at the ml10m shape).
 #pragma once
 #include "hsk_common.h"
+#if defined(__HIPCC__)
+#include <rocprim/block/block_radix_sort.hpp>
+#endif
 
 #define HSK_SORT_MAX_BUCKETS 512
 #define HSK_SORT_MAX_UNITS 512
@@ -265,6 +268,51 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
     const int q = c + lane;
     place((q < whi) ? perm1[q] : make_int2(-1, -1));
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Small batches (<= 1024 * IPT entries): the whole sort in ONE workgroup.  At B = 128, N = 50 the four level-1/2
+// kernels above are 43 us of launch latencies for 6 528 entries -- longer than the rest of the step.  A stable block
+// radix sort (rocPRIM's block primitive; blocked arrangement, so equal items keep ascending entry order) of
+// (item, entry) gives perm directly; offsets come from the run boundaries of the sorted keys.
+// ---------------------------------------------------------------------------------------------
+template <int IPT>
+__global__ __launch_bounds__(1024) void k_sort_small(const int* __restrict__ it32, int n_entries, int n_items,
+                                                     int nbits, int* __restrict__ perm, int* __restrict__ offsets) {
+  using sort_t = rocprim::block_radix_sort<unsigned int, 1024, IPT, int>;
+  __shared__ typename sort_t::storage_type storage;
+  const int tid = threadIdx.x;
+  unsigned int keys[IPT];
+  int vals[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int e = tid * IPT + j;
+    keys[j] = (e < n_entries) ? (unsigned int)it32[e] : (unsigned int)n_items;   // pads sort behind every item
+    vals[j] = e;
+  }
+  sort_t().sort(keys, vals, storage, 0, nbits);
+  __shared__ unsigned int last_key[1024];
+  last_key[tid] = keys[IPT - 1];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int pos = tid * IPT + j;
+    if (pos < n_entries) perm[pos] = vals[j];
+  }
+  __syncthreads();
+  // offsets from the run boundaries of the sorted keys (in registers): where the key steps from p to c at position
+  // pos, every item in (p, c] starts at pos (items without entries included).  The first padding key (n_items, at
+  // position n_entries) closes the list: offsets[n_items] = n_entries.
+  int prev = tid ? (int)last_key[tid - 1] : -1;
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int pos = tid * IPT + j;
+    const int cur = (int)keys[j];
+    for (int i = prev + 1; i <= cur; ++i) offsets[i] = pos;
+    prev = cur;
+  }
+  if (tid == 1023 && n_entries == 1024 * IPT)   // no padding key: close the list here
+    for (int i = prev + 1; i <= n_items; ++i) offsets[i] = n_entries;
 }
 
 #endif  // __HIPCC__
