@@ -177,14 +177,19 @@ def main():
     n_batches = nnz // (B * world)
 
     def run(n, first):
+        if world == 1:
+            # the epoch's inner loop, issued from C in runs of consecutive batches (hsk_bprmf_train_steps: each step
+            # hints the next one to the prefetch); a run ends where the epoch order wraps around
+            s = 0
+            while s < n:
+                k0 = (first + s) % n_batches
+                m = min(n - s, n_batches - k0, 256)
+                st.steps_sampled(order, k0 * B, m, B, N)
+                s += m
+            return
         for s in range(n):
             start = ((first + s) % n_batches) * B * world        # global batch = world * B positives (weak scaling)
-            if world == 1:
-                if s + 1 < n:   # the epoch loop knows its next batch: let this step prepare it on the side stream
-                    st.hint_next(order, ((first + s + 1) % n_batches) * B, B, N)
-                st.step_sampled(order, start, B, N)
-            else:
-                st.step_sampled(order, start)
+            st.step_sampled(order, start)
 
     def fence():
         if comm is not None:

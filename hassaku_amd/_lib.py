@@ -78,6 +78,8 @@ SIGNATURES = {
     'hsk_bprmf_train_step': (c_int, [POINTER(HskBprmfState), c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hsk_bprmf_train_step_sampled': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64,
                                              c_void_p]),
+    'hsk_bprmf_train_steps': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                      c_void_p]),
     'hsk_timing_create': (c_void_p, []),
     'hsk_timing_destroy': (None, [c_void_p]),
     'hsk_timing_collect': (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),

@@ -687,6 +687,23 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   return hsk_run_step(st, w, set, false, batch, n_neg + 1, stream);
 }
 
+extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t n_steps,
+                                     int64_t batch, int64_t n_neg, hsk_stream_t stream_) {
+  HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
+  HSK_REQUIRE(n_steps >= 0 && batch > 0 && start >= 0 && start + n_steps * batch <= st->nnz, HSK_ERR_INVALID,
+              "steps [%lld, +%lld x %lld) outside nnz %lld", (long long)start, (long long)n_steps, (long long)batch,
+              (long long)st->nnz);
+  for (int64_t s = 0; s < n_steps; ++s) {
+    if (st->aux && s + 1 < n_steps) {
+      int hrc = hsk_bprmf_hint_next(st, order, start + (s + 1) * batch, batch, n_neg);
+      if (hrc) return hrc;
+    }
+    int rc = hsk_bprmf_train_step_sampled(st, order, start + s * batch, batch, n_neg, stream_);
+    if (rc) return rc;
+  }
+  return HSK_OK;
+}
+
 extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
   int rc = hsk_check_state(st);
   if (rc) return rc;

@@ -382,6 +382,16 @@ class BprMfFusedState:
         _lib.check(self.lib.hsk_bprmf_train_step_sampled(ctypes.byref(self.st), _p(order), start, batch, n_neg,
                                                          _stream()), 'hsk_bprmf_train_step_sampled')
 
+    def steps_sampled(self, order: Optional[torch.Tensor], start: int, n_steps: int, batch: int, n_neg: int):
+        """n_steps fused steps on consecutive batches of `batch` positives starting at order[start] -- the epoch's
+        inner loop issued from C (each step hints the next one to the prefetch)."""
+        if order is not None:
+            _chk(order, torch.int64, 'order')
+            if start + n_steps * batch > order.numel():
+                raise ValueError('order too short')
+        _lib.check(self.lib.hsk_bprmf_train_steps(ctypes.byref(self.st), _p(order), start, n_steps, batch, n_neg,
+                                                  _stream()), 'hsk_bprmf_train_steps')
+
     def hint_next(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int):
         """Name the batch of the NEXT step_sampled call so that the step issued now prepares it on the side stream.
         No-op without overlap=True.  batch <= 0 clears a pending hint."""

@@ -175,10 +175,20 @@ class Trainer:
             # the loader knows its next batch: each step samples + sorts it on the side stream (device-side
             # counterpart of the reference's DataLoader prefetch, train/trainer.py:127-130)
             batches = list(loader.fused_batches())
-            for k, (order, start, nb) in enumerate(batches):
-                if k + 1 < len(batches):
+            k = 0
+            while k < len(batches):
+                order, start, nb = batches[k]
+                run = 1                                   # consecutive full batches go down in one C call
+                while (k + run < len(batches) and run < 256 and batches[k + run][2] == nb
+                       and batches[k + run][1] == start + run * nb and batches[k + run][0] is order):
+                    run += 1
+                if k + run < len(batches) and run == 1:
                     fused.hint_next(*batches[k + 1], n_neg)
-                fused.step_sampled(order, start, nb, n_neg)
+                if run > 1:
+                    fused.steps_sampled(order, start, run, nb, n_neg)
+                else:
+                    fused.step_sampled(order, start, nb, n_neg)
+                k += run
         else:
             for u_idxs, i_idxs, _labels in loader:
                 fused.step(u_idxs.to(self.device), i_idxs.to(self.device))

@@ -266,6 +266,13 @@ void hsk_aux_destroy(void* aux);
  * Needs st->aux; `order` must stay valid and unchanged until the hinted step has been issued. */
 int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch, int64_t n_neg);
 
+/* n_steps consecutive hsk_bprmf_train_step_sampled calls on the batches order[start + s*batch .. +batch), s < n_steps,
+ * each hinting the next one to the prefetch (when st->aux is set): the inner loop of an epoch (train/trainer.py:128-148)
+ * issued from C.  At small batches the step is bound by the host's launch rate (ten HIP calls of 3-4 us each plus the
+ * interpreter), not by the GPU; this removes the interpreter's share. */
+int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t n_steps, int64_t batch,
+                          int64_t n_neg, hsk_stream_t stream);
+
 /* Bring lazily-updated user rows up to st->step (no-op when lazy_users == 0). */
 int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
 

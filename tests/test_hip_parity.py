@@ -351,6 +351,36 @@ def test_prefetched_batches_change_nothing(ops):
         assert np.array_equal(base[k], pref[k]), k
 
 
+def test_multi_step_call_equals_single_steps(ops):
+    """hsk_bprmf_train_steps (the epoch's inner loop issued from C) == the same steps issued one by one."""
+    rng = np.random.RandomState(4)
+    n_users, n_items, D, B, N = 150, 260, 96, 64, 70
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.15)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
+    order = torch.from_numpy(np.random.RandomState(6).permutation(len(pairs))).cuda()
+    res = []
+    for chunked in (False, True):
+        st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                             coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+        if chunked:
+            st.steps_sampled(order, 0, 40, B, N)
+            st.steps_sampled(order, 40 * B, 30, B, N)
+        else:
+            for s in range(70):
+                st.step_sampled(order, s * B, B, N)
+        st.flush()
+        st.check_status()
+        assert st.step_count == 70
+        res.append(({k: v.cpu().numpy().copy() for k, v in t.items()}, st.pop_loss_sum()))
+    assert res[0][1] == res[1][1]
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+
+
 def test_wrong_hints_are_discarded(ops):
     """A hint that does not match the next call (or is followed by an external batch) costs time, never results."""
     base, b0, l0 = _run_sampled_epoch(ops, overlap=True, hints=None)
