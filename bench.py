@@ -37,7 +37,7 @@ WORKLOADS = {
     'hbm': ('hbm', 512, 100, 4096),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = 'r1d_duplists'  # committed rocprofv3 summaries of `bench.py` (profiles/README.md)
+PROFILE_DIR = 'r1e_final'  # committed rocprofv3 summaries of `bench.py` (profiles/README.md)
 LR, WD = 3e-4, 4e-5    # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
