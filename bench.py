@@ -33,6 +33,7 @@ WORKLOADS = {
     'ml100k': ('ml100k', 64, 1, 128),
     'ml1m': ('ml1m', 402, 50, 128),
     'ml10m': ('ml10m', 512, 100, 4096),
+    'lfm2b': ('lfm2b', 512, 100, 4096),   # the BASELINE configs[3] catalogue (131 072 items) under the configs[2] step
     # not a BASELINE config: the ml10m step on tables that cannot be cached (the honest HBM point for k_fwd_ugrad)
     'hbm': ('hbm', 512, 100, 4096),
 }
