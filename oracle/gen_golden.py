@@ -88,6 +88,7 @@ def gen_g1():
         ('d64_all', 64, 40, 130, 16, 7, True, True, True),
         ('d30_none', 30, 33, 101, 9, 3, False, False, False),
         ('d64_dups', 64, 6, 20, 32, 9, False, True, False),   # heavy duplicate users / items in a batch
+        ('d512_n100', 512, 16, 120, 8, 100, False, True, False),   # the BASELINE configs[2] row shape (D=512, 100 negatives)
     ]
     lr, wd = 3e-4, 4e-5
     for tag, D, U, I, B, N, ub, ib, gb in cases:

@@ -69,7 +69,7 @@ def assert_adam_param_close(got, ref, what='', max_tol=None):
     assert (err > 1e-5).mean() <= ADAM_FRAC, (what, 'fraction beyond 1e-5', (err > 1e-5).mean())
 
 
-G1_CASES = ['d16_item', 'd64_item', 'd402_item', 'd64_all', 'd30_none', 'd64_dups']
+G1_CASES = ['d16_item', 'd64_item', 'd402_item', 'd64_all', 'd30_none', 'd64_dups', 'd512_n100']
 PARAM_KEYS = {  # state_dict key -> short name used by the oracle / fused state
     'user_embeddings.weight': 'user_emb', 'item_embeddings.weight': 'item_emb',
     'item_bias.weight': 'item_bias', 'user_bias.weight': 'user_bias', 'global_bias': 'global_bias'}
