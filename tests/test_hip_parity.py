@@ -158,9 +158,14 @@ def test_fused_replay_of_reference_fit(ops, oracle):
 
 
 @pytest.mark.parametrize('D,U,I,B,N', [(512, 300, 500, 256, 100), (402, 200, 333, 128, 50), (64, 100, 150, 128, 1),
-                                        (1024, 64, 200, 32, 200), (33, 50, 101, 17, 3), (6, 20, 100, 5, 130)])
+                                        (1024, 64, 200, 32, 200), (33, 50, 101, 17, 3), (6, 20, 100, 5, 130),
+                                        # B > 1024: the one-wave-per-positive forward (smaller batches with >= 9
+                                        # columns take the workgroup-per-positive kernel)
+                                        (402, 300, 333, 1100, 50), (1024, 64, 200, 1040, 20), (33, 50, 101, 1030, 12),
+                                        (2048, 40, 90, 24, 30)])
 def test_fused_step_vs_oracle_random_shapes(ops, oracle, D, U, I, B, N):
-    """BASELINE config shapes (D=512/N=100, D=402/N=50, D=64/N=1, D=1024/N=200) and odd sizes, 2 steps."""
+    """BASELINE config shapes (D=512/N=100, D=402/N=50, D=64/N=1, D=1024/N=200), odd sizes, the largest supported
+    row (D=2048), both forward kernels; 2 steps."""
     rng = np.random.RandomState(D + B)
     P = {'user_emb': (rng.randn(U, D) * 0.1).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.1).astype(np.float32),
          'item_bias': (rng.randn(I) * 0.1).astype(np.float32)}
