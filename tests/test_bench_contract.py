@@ -1,0 +1,35 @@
+"""The driver's contract with bench.py: one JSON line, the agreed keys, the roofline and cpu_baseline objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--workload', 'ml100k', '--steps', '6',
+                          '--warmup', '2', '--cpu-budget', '1'], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['metric'] == 'BPR triplets/sec' and d['unit'] == 'triplets/s' and d['higher_is_better'] is True
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 2 and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert d['value'] > 0 and abs(d['value'] * d['ms_per_step'] * 1e-3 - 128 * 1) < 1e-6 * 128      # B=128, N=1
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
