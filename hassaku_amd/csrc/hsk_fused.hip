@@ -43,6 +43,8 @@ struct hsk_ws {
   double* loss_b;
   float2* adam_tab;
   int *dupcnt, *duplist;   // per owner entry: how many / which further entries name the same user
+  int* last_step_i;        // lazy item AdamW: steps already applied to each item row
+  int *touched, *n_touched, *touched_b, *n_touched_b;   // per buffer set: items with entries (compact), their count
   // second set of the per-batch buffers: the next batch is sampled and sorted into it while this one trains
   int *u32_b, *it32_b, *perm_b, *hist_b, *btot_b, *bstart_b, *offsets_b, *owner_b, *cnt_b;
   int2* perm1_b;
@@ -63,6 +65,8 @@ static inline hsk_ws hsk_select(const hsk_ws& w, int set) {
   std::swap(r.offsets, r.offsets_b);
   std::swap(r.owner, r.owner_b);
   std::swap(r.cnt, r.cnt_b);
+  std::swap(r.touched, r.touched_b);
+  std::swap(r.n_touched, r.n_touched_b);
   return r;
 }
 
@@ -95,6 +99,11 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.adam_tab = (float2*)take((HSK_ADAM_TAB_LEN + 1) * sizeof(float2));
   w.dupcnt = (int*)take(max_batch * 4);
   w.duplist = (int*)take(max_batch * HSK_DUP_MAX * 4);
+  w.last_step_i = (int*)take(n_items * 4);
+  w.touched = (int*)take(ent * 4);
+  w.touched_b = (int*)take(ent * 4);
+  w.n_touched = (int*)take(256);
+  w.n_touched_b = (int*)take(256);
   w.u32_b = (int*)take(max_batch * 4);
   w.it32_b = (int*)take(ent * 4);
   w.perm1_b = (int2*)take(ent * 8);
@@ -154,6 +163,9 @@ static int hsk_check_state(const hsk_bprmf_state* st) {
   HSK_REQUIRE(st->step >= 0 && st->step < 0x7ffffff0, HSK_ERR_UNSUPPORTED, "step counter out of range");
   HSK_REQUIRE(st->loss_kind >= HSK_LOSS_BPR && st->loss_kind <= HSK_LOSS_SSM, HSK_ERR_INVALID, "unknown loss_kind %d",
               st->loss_kind);
+  HSK_REQUIRE(st->lazy_items == 0 || st->lazy_items == 1, HSK_ERR_INVALID, "lazy_items must be 0 or 1");
+  HSK_REQUIRE(st->lazy_items == 0 || (st->dim % 2 == 0 && hsk_adam_tab_saturates(st)), HSK_ERR_UNSUPPORTED,
+              "lazy_items needs an even dim and bias corrections that saturate within %d steps", HSK_ADAM_TAB_LEN);
   HSK_REQUIRE(st->opt_kind >= HSK_OPT_ADAMW && st->opt_kind <= HSK_OPT_ADAGRAD, HSK_ERR_INVALID, "unknown opt_kind %d",
               st->opt_kind);
   HSK_REQUIRE((st->alias_prob == nullptr) == (st->alias_idx == nullptr), HSK_ERR_INVALID,
@@ -169,6 +181,9 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   HSK_HIP(hipMemsetAsync(w.cnt, 0, st->n_users * 4, stream));
   HSK_HIP(hipMemsetAsync(w.cnt_b, 0, st->n_users * 4, stream));
   HSK_HIP(hipMemsetAsync(w.dupcnt, 0, st->max_batch * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.n_touched, 0, 4, stream));
+  HSK_HIP(hipMemsetAsync(w.n_touched_b, 0, 4, stream));
+  k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_items, 256), 256, 0, stream>>>(w.last_step_i, st->n_items, (int)st->step);
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner, st->n_users, HSK_OWNER_NONE);
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner_b, st->n_users, HSK_OWNER_NONE);
   HSK_LAUNCH_CHECK();
@@ -343,12 +358,25 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
                                                          st->m_user_bias, st->v_user_bias, w.last_step, U, D,         \
                                                          (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN)
   const bool gen = st->opt_kind != HSK_OPT_ADAMW;
-  if (D % 2 == 0) {
-    if (gen) HSK_FLUSH(2, true); else HSK_FLUSH(2, false);
-  } else {
-    if (gen) HSK_FLUSH(1, true); else HSK_FLUSH(1, false);
+  if (st->lazy_users) {
+    if (D % 2 == 0) {
+      if (gen) HSK_FLUSH(2, true); else HSK_FLUSH(2, false);
+    } else {
+      if (gen) HSK_FLUSH(1, true); else HSK_FLUSH(1, false);
+    }
   }
 #undef HSK_FLUSH
+  if (st->lazy_items) {   // the same sweep over the item table (even dim guaranteed by hsk_check_state)
+    const int I = (int)st->n_items;
+    if (gen)
+      k_user_flush<2, true><<<(unsigned)I, 256, 0, stream>>>(st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias,
+                                                            st->m_item_bias, st->v_item_bias, w.last_step_i, I, D,
+                                                            (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN);
+    else
+      k_user_flush<2, false><<<(unsigned)I, 256, 0, stream>>>(st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias,
+                                                             st->m_item_bias, st->v_item_bias, w.last_step_i, I, D,
+                                                             (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN);
+  }
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
@@ -359,7 +387,8 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
 // `Urows` / `urow_index`: where the batch's user rows live (the table + u32, or the exchange buffer + slot_of_b).
 template <int V, int NCH, bool FULL, int R, bool APPLY>
 static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, const float* Urows, const int* urow_index,
-                                 int K, const hsk_adamw_consts& c, float* gI_out, float* gIb_out, hipStream_t stream) {
+                                 int K, const hsk_adamw_consts& c, float* gI_out, float* gIb_out, hipStream_t stream,
+                                 int64_t n_entries = 0) {
   const int I = (int)st->n_items, D = (int)st->dim;
   if (D % 2 != 0) {
     k_item_update<V, NCH, FULL, R, APPLY><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
@@ -376,6 +405,22 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
       Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,     \
       urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, 1, c, gI_out, gIb_out)
   const bool gen = APPLY && st->opt_kind != HSK_OPT_ADAMW;   // APPLY == false never calls the update
+  if (APPLY && st->lazy_items) {
+    // lazy item AdamW: only the items with entries (the sort's `touched` list; at most one per entry)
+    const unsigned lgroups = (unsigned)hsk_align_up(hsk_ceil_div(std::min<int64_t>(I, n_entries), 4), 8);
+#define HSK_ITEM_SLICED_LAZY(VS, GEN)                                                                          \
+  k_item_update_sliced<APPLY, VS, GEN, true><<<lgroups * n_slices_pad, 256, 0, stream>>>(                       \
+      Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,     \
+      urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, 1, c, gI_out, gIb_out, w.touched,            \
+      w.n_touched, w.last_step_i, (int)st->step)
+    if (vs == 4) {
+      if (gen) HSK_ITEM_SLICED_LAZY(4, true); else HSK_ITEM_SLICED_LAZY(4, false);
+    } else {
+      if (gen) HSK_ITEM_SLICED_LAZY(2, true); else HSK_ITEM_SLICED_LAZY(2, false);
+    }
+#undef HSK_ITEM_SLICED_LAZY
+    return;
+  }
   if (vs == 4) {
     if (gen) HSK_ITEM_SLICED(4, true); else HSK_ITEM_SLICED(4, false);
   } else {
@@ -409,22 +454,25 @@ static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t t
     // one workgroup sorts the whole batch (see k_sort_small)
     int nbits = 1;
     while ((1ll << nbits) <= (long long)I) ++nbits;   // keys 0..I (I = padding) fit
+    int* tl = st->lazy_items ? w.touched : nullptr;
+    int* tn = st->lazy_items ? w.n_touched : nullptr;
     HSK_STAGE(HSK_STAGE_SCATTER, {
       if (total <= 1024 * 2)
-        k_sort_small<2><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets);
+        k_sort_small<2><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn);
       else if (total <= 1024 * 4)
-        k_sort_small<4><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets);
+        k_sort_small<4><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn);
       else
-        k_sort_small<8><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets);
+        k_sort_small<8><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn);
     });
     HSK_LAUNCH_CHECK();
     return HSK_OK;
   }
   hsk_sort_plan plan;
   HSK_REQUIRE(hsk_make_sort_plan(I, total, &plan) == 0, HSK_ERR_UNSUPPORTED, "item sort: n_items too large");
-  const size_t bucket_lds = (size_t)5 * plan.ipb * sizeof(int);
+  const size_t bucket_lds = ((size_t)(st->lazy_items ? 6 : 5) * plan.ipb + 2) * sizeof(int);
   if (bucket_lds > 65536)
     HSK_HIP(hipFuncSetAttribute((const void*)k_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds));
+  if (st->lazy_items) HSK_HIP(hipMemsetAsync(w.n_touched, 0, sizeof(int), stream));
   HSK_STAGE(HSK_STAGE_SCAN, {
     k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist);
     k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
@@ -433,8 +481,9 @@ static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t t
   HSK_STAGE(HSK_STAGE_SCATTER, {
     k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist, w.btot,
                                                                                  w.perm1, w.bstart);
-    k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(w.perm1, (int)total, I, plan, w.bstart, w.perm,
-                                                                         w.offsets);
+    k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(
+        w.perm1, (int)total, I, plan, w.bstart, w.perm, w.offsets, st->lazy_items ? w.touched : nullptr,
+        st->lazy_items ? w.n_touched : nullptr);
   });
   HSK_LAUNCH_CHECK();
   return HSK_OK;
@@ -512,6 +561,22 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   if (!sorted) {
     int src = hsk_launch_sort(st, w, total, stream);
     if (src) return src;
+  }
+  if (st->lazy_items) {
+    // the forward must read current item rows too: replay the missed zero-gradient steps of this batch's items
+    // (the list the sort left in w.touched)
+    const unsigned nblk = (unsigned)std::min<int64_t>(st->n_items, total);
+    if (gen)
+      HSK_STAGE(HSK_STAGE_ITEM, (k_item_catch_up<2, true><<<nblk, 256, 0, stream>>>(
+                                    st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias, st->m_item_bias,
+                                    st->v_item_bias, w.touched, w.n_touched, w.last_step_i, D, (int)st->step, c,
+                                    w.adam_tab, HSK_ADAM_TAB_LEN)));
+    else
+      HSK_STAGE(HSK_STAGE_ITEM, (k_item_catch_up<2, false><<<nblk, 256, 0, stream>>>(
+                                    st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias, st->m_item_bias,
+                                    st->v_item_bias, w.touched, w.n_touched, w.last_step_i, D, (int)st->step, c,
+                                    w.adam_tab, HSK_ADAM_TAB_LEN)));
+    HSK_LAUNCH_CHECK();
   }
   if (hsk_pf_early(B)) {
     int prc = hsk_launch_prefetch(st, w_all, set, stream);
@@ -596,7 +661,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     constexpr bool FULL = decltype(f_)::value;
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
     HSK_STAGE(HSK_STAGE_ITEM, hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, st->user_emb, w.u32, (int)K, c, nullptr,
-                                                                          nullptr, stream));
+                                                                          nullptr, stream, total));
     if (st->lazy_users) {
       // + one workgroup for the loss reduction / global bias (no separate finish launch in lazy mode)
       const hsk_finish_args fin = {w.loss_b, (int)B, inv_bn_d, st->loss_out, st->global_bias, st->m_global_bias,
@@ -623,7 +688,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
                                                                        st->v_global_bias, c));
     HSK_LAUNCH_CHECK();
   }
-  if (st->lazy_users && (st->step % HSK_FLUSH_EVERY) == 0) {
+  if ((st->lazy_users || st->lazy_items) && (st->step % HSK_FLUSH_EVERY) == 0) {
     int frc = 0;
     HSK_STAGE(HSK_STAGE_USER, frc = hsk_launch_flush(st, w, stream));
     if (frc) return frc;
@@ -707,7 +772,7 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
 extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
   int rc = hsk_check_state(st);
   if (rc) return rc;
-  if (!st->lazy_users) return HSK_OK;  // dense user updates: nothing is pending
+  if (!st->lazy_users && !st->lazy_items) return HSK_OK;  // dense updates: nothing is pending
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   return hsk_launch_flush(st, w, (hipStream_t)stream_);
 }

@@ -10,7 +10,8 @@
 #pragma once
 #include "hsk_rows.h"
 
-template <bool APPLY, int VS, bool GEN>   // VS floats per lane: slice width = 64*VS floats; GEN: see hsk_adamw_update
+template <bool APPLY, int VS, bool GEN, bool LAZY = false>   // VS floats per lane: slice width = 64*VS floats; GEN: see
+                                                            // hsk_adamw_update; LAZY: only the items in `touched`
 __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restrict__ Uw, float* __restrict__ Iw,
                                                             float* __restrict__ Ib, float* __restrict__ mI,
                                                             float* __restrict__ vI, float* __restrict__ mIb,
@@ -18,7 +19,10 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
                                                             const float* __restrict__ g_s, const int* __restrict__ perm,
                                                             const int* __restrict__ offsets, int n_items, int K, int D,
                                                             int n_slices_pad, int items_per_wave, hsk_adamw_consts c,
-                                                            float* __restrict__ gI_out, float* __restrict__ gIb_out) {
+                                                            float* __restrict__ gI_out, float* __restrict__ gIb_out,
+                                                            const int* __restrict__ touched = nullptr,
+                                                            const int* __restrict__ n_touched = nullptr,
+                                                            int* __restrict__ last_step_i = nullptr, int step = 0) {
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   // n_slices_pad = number of slices when it divides 8 (each slice then owns 8/n XCDs), else a multiple of 8
@@ -36,9 +40,13 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
   const bool live = d < D;                       // the last slice may be partial (D % VS == 0); padded slices are empty
   if (slice * SW >= D) return;
   const int first = (group * 4 + wave) * items_per_wave;
+  const int n_list = LAZY ? hsk_uniform_i(*n_touched) : n_items;
   for (int t = 0; t < items_per_wave; ++t) {
-    const int i = first + t;
-    if (i >= n_items) return;
+    const int idx = first + t;
+    if (idx >= n_list) return;
+    // lazy item AdamW: only the items that have entries are visited (their rows were brought up to step-1 by
+    // k_item_catch_up); the others keep their zero-gradient steps for later
+    const int i = LAZY ? hsk_uniform_i(touched[idx]) : idx;
     const int beg = hsk_uniform_i(offsets[i]);
     const int end = hsk_uniform_i(offsets[i + 1]);
     // AdamW operands early: their latency hides under the gather
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
           vIb[i] = vb;
         }
       }
+      if (LAZY && slice == 0 && lane == 0) last_step_i[i] = step;
     } else {
       if (live) hsk_stg<VS>(gI_out + (long long)i * D + d, acc);
       if (slice == 0 && gIb_out) {

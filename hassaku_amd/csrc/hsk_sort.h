@@ -188,11 +188,18 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const int* __restrict__ it
 
 __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ perm1, int n_entries, int n_items,
                                                      hsk_sort_plan p, const int* __restrict__ bstart,
-                                                     int* __restrict__ perm, int* __restrict__ offsets) {
-  extern __shared__ int lds[];  // cnt[4][ipb] then tot[ipb]
+                                                     int* __restrict__ perm, int* __restrict__ offsets,
+                                                     int* __restrict__ touched = nullptr,
+                                                     int* __restrict__ n_touched = nullptr) {
+  // touched / n_touched (optional): compact list of the items that have entries, any order (lazy item AdamW:
+  // hsk_fused.hip); needs ipb + 2 more ints of dynamic LDS
+  extern __shared__ int lds[];  // cnt[4][ipb] then tot[ipb] [then list[ipb], count, base]
   const int ipb = p.ipb;
   int* cnt = lds;
   int* tot = lds + 4 * ipb;
+  int* tlist = lds + 5 * ipb;
+  int* tmeta = lds + 6 * ipb;   // [0] items with entries in this bucket, [1] their base in `touched`
+  if (touched && threadIdx.x == 0) tmeta[0] = 0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int b = blockIdx.x;
   const int beg = bstart[b], end = bstart[b + 1];
@@ -218,6 +225,7 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
   for (int j = tid; j < ipb; j += 256) {
     const int c0 = cnt[j], c1 = cnt[ipb + j], c2 = cnt[2 * ipb + j], c3 = cnt[3 * ipb + j];
     tot[j] = c0 + c1 + c2 + c3;
+    if (touched && c0 + c1 + c2 + c3 > 0) tlist[atomicAdd(&tmeta[0], 1)] = item0 + j;
     cnt[j] = 0;
     cnt[ipb + j] = c0;
     cnt[2 * ipb + j] = c0 + c1;
@@ -245,7 +253,10 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
     cnt[3 * ipb + j] += start;
   }
   if (b == p.n_buckets - 1 && tid == 0) offsets[n_items] = n_entries;
+  if (touched && tid == 0) tmeta[1] = atomicAdd(n_touched, tmeta[0]);
   __syncthreads();
+  if (touched)
+    for (int j = tid; j < tmeta[0]; j += 256) touched[tmeta[1] + j] = tlist[j];
   const int nbits = hsk_bits_for(ipb);
   int* run = cnt + w * ipb;
   auto place = [&](int2 ent) {   // one chunk of 64 entries, in order
@@ -279,7 +290,9 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
 // ---------------------------------------------------------------------------------------------
 template <int IPT>
 __global__ __launch_bounds__(1024) void k_sort_small(const int* __restrict__ it32, int n_entries, int n_items,
-                                                     int nbits, int* __restrict__ perm, int* __restrict__ offsets) {
+                                                     int nbits, int* __restrict__ perm, int* __restrict__ offsets,
+                                                     int* __restrict__ touched = nullptr,
+                                                     int* __restrict__ n_touched = nullptr) {
   using sort_t = rocprim::block_radix_sort<unsigned int, 1024, IPT, int>;
   __shared__ typename sort_t::storage_type storage;
   const int tid = threadIdx.x;
@@ -293,6 +306,8 @@ __global__ __launch_bounds__(1024) void k_sort_small(const int* __restrict__ it3
   }
   sort_t().sort(keys, vals, storage, 0, nbits);
   __shared__ unsigned int last_key[1024];
+  __shared__ int nt;
+  if (tid == 0) nt = 0;
   last_key[tid] = keys[IPT - 1];
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
@@ -309,7 +324,12 @@ __global__ __launch_bounds__(1024) void k_sort_small(const int* __restrict__ it3
     const int pos = tid * IPT + j;
     const int cur = (int)keys[j];
     for (int i = prev + 1; i <= cur; ++i) offsets[i] = pos;
+    if (touched && cur != prev && cur < n_items) touched[atomicAdd(&nt, 1)] = cur;   // first entry of item `cur`
     prev = cur;
+  }
+  if (touched) {
+    __syncthreads();
+    if (tid == 0) *n_touched = nt;
   }
   if (tid == 1023 && n_entries == 1024 * IPT)   // no padding key: close the list here
     for (int i = prev + 1; i <= n_items; ++i) offsets[i] = n_entries;

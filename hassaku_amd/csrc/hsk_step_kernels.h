@@ -452,6 +452,36 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
   }
 }
 
+// Lazy ITEM AdamW (catalogues far larger than a batch touches): the items of this batch -- the compact list the item
+// sort leaves in `touched` -- are brought up to step-1 before the forward reads them; every other item row keeps its
+// zero-gradient steps for later, exactly like the user rows above.  One workgroup per listed item.
+template <int VV, bool GEN>
+__global__ __launch_bounds__(256) void k_item_catch_up(float* __restrict__ Iw, float* __restrict__ mI,
+                                                       float* __restrict__ vI, float* __restrict__ Ib,
+                                                       float* __restrict__ mIb, float* __restrict__ vIb,
+                                                       const int* __restrict__ touched,
+                                                       const int* __restrict__ n_touched, int* __restrict__ last_step_i,
+                                                       int D, int step, hsk_adamw_consts c,
+                                                       const float2* __restrict__ tab, int tab_len) {
+  if ((int)blockIdx.x >= *n_touched) return;
+  const int row = touched[blockIdx.x];
+  const int done = last_step_i[row];
+  if (done >= step - 1) return;
+  hsk_row_replay_wg<VV, GEN>(Iw + (long long)row * D, mI + (long long)row * D, vI + (long long)row * D, D, done, step - 1,
+                             c, tab, tab_len);
+  __syncthreads();  // every thread has read last_step_i[row]
+  if (threadIdx.x == 0) {
+    if (Ib) {
+      float pb = Ib[row], mb = mIb[row], vb = vIb[row];
+      for (int t = done + 1; t <= step - 1; ++t) hsk_adamw_update<GEN>(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
+      Ib[row] = pb;
+      mIb[row] = mb;
+      vIb[row] = vb;
+    }
+    last_step_i[row] = step - 1;
+  }
+}
+
 // Tail work of a step that rides on the last launch as one extra workgroup (saves a dependent launch): deterministic
 // fp64 tree sum of the per-positive loss terms and the zero-gradient AdamW step of the global bias.
 struct hsk_finish_args {

@@ -283,7 +283,7 @@ class BprMfFusedState:
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=None, seed=0,
                  csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=True,
-                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw'):
+                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto'):
         _lib.require_gpu()
         if optimizer not in OPT_KINDS:
             raise ValueError(f'Optimizer {optimizer} not yet implemented')
@@ -326,6 +326,9 @@ class BprMfFusedState:
         st.n_users, st.n_items, st.dim = n_users, n_items, dim
         st.lr, st.beta1, st.beta2, st.eps, st.wd = lr, beta1, beta2, eps, wd
         st.opt_kind = OPT_KINDS[optimizer]
+        if lazy_items == 'auto':   # worth it when most item rows are outside every batch
+            lazy_items = dim % 2 == 0 and n_items >= 2 * self.max_batch * self.max_cols
+        st.lazy_items = 1 if lazy_items else 0
         st.step = 0
         st.csr_indptr, st.csr_indices = _p(csr_indptr), _p(csr_indices)
         st.coo_user, st.coo_item = _p(coo_user), _p(coo_item)

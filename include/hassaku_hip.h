@@ -210,6 +210,11 @@ typedef struct hsk_bprmf_state {
      (alias_prob float[I], alias_idx int32[I]) = train_neg_strategy 'popular' (data/dataloader.py:59-64) */
   const float* alias_prob;
   const int32_t* alias_idx;
+  /* 1: lazy, exact AdamW on the ITEM tables too (same scheme as lazy_users: a row outside the batch keeps its
+     zero-gradient steps until it is next touched or flushed; bit-identical to the dense update).  For catalogues far
+     larger than a batch touches; needs an even dim.  0 (default): every item row is updated every step */
+  int32_t lazy_items;
+  int32_t reserved2;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;

@@ -236,6 +236,29 @@ def test_lazy_user_adamw_is_bitwise_the_dense_sweep(ops):
         assert np.array_equal(dense[k], lazy[k]), k
 
 
+@pytest.mark.parametrize('opt', ['adamw', 'adagrad'])
+def test_lazy_item_adamw_is_bitwise_the_dense_update(ops, opt):
+    """lazy_items: item rows outside the batch keep their zero-gradient steps until they are next touched or flushed --
+    bit-identical to updating every item row every step (150 steps: across the flush at 64 and 128), with the two-level
+    sort (I=3000 items, 48 x 10 entries: most rows untouched) and with the single-workgroup sort."""
+    for kw in (dict(U=300, I=3000, D=64, B=48, N=9), dict(U=120, I=900, D=32, B=1000, N=9)):
+        dense, l0 = _run_random_steps(ops, 150, lazy=True, lazy_items=False, optimizer=opt, **kw)
+        lazy, l1 = _run_random_steps(ops, 150, lazy=True, lazy_items=True, optimizer=opt, **kw)
+        assert l0 == l1
+        for k in dense:
+            assert np.array_equal(dense[k], lazy[k]), (k, kw)
+
+
+def test_lazy_items_with_the_device_sampler_and_prefetch(ops):
+    """The touched-item list is built by the sort on the side stream (next batch) while the current batch's list is in
+    use: same batches, losses and tables as the dense item update."""
+    base, b0, l0 = _run_sampled_epoch(ops, overlap=True, hints='right', lazy_items=False)
+    lazy, b1, l1 = _run_sampled_epoch(ops, overlap=True, hints='right', lazy_items=True)
+    assert l0 == l1
+    for k in base:
+        assert np.array_equal(base[k], lazy[k]), k
+
+
 def test_fused_step_is_bitwise_reproducible(ops):
     """No atomics on the data path: two runs of the same batches give identical bits."""
     a, la = _run_random_steps(ops, 40, lazy=True, seed=9, U=80, I=37, B=64, N=30)   # ~50 entries per item
@@ -306,7 +329,7 @@ def test_sampler_user_with_all_items_gives_up(ops):
         ops.raise_on_status(status)
 
 
-def _run_sampled_epoch(ops, overlap, hints, steps=70):
+def _run_sampled_epoch(ops, overlap, hints, steps=70, **kw):
     """`steps` device-sampled steps over a fixed interaction order; hints: None | 'right' | 'mixed'."""
     rng = np.random.RandomState(4)
     n_users, n_items, D, B, N = 150, 260, 96, 64, 70     # 64 x 71 entries: above the prefetch minimum (4096)
@@ -318,7 +341,7 @@ def _run_sampled_epoch(ops, overlap, hints, steps=70):
          'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
          'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
     st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, overlap=overlap, csr_indptr=dev(ptr), csr_indices=dev(idx),
-                         coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+                         coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32), **kw)
     order = torch.from_numpy(np.random.RandomState(6).permutation(len(pairs))).cuda()
     batches, losses = [], []
     for s in range(steps):
