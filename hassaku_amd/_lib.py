@@ -42,18 +42,19 @@ class HskBprmfState(ctypes.Structure):
     ]
 
 
-class HskBprmfMp(ctypes.Structure):
-    """Mirror of `struct hsk_bprmf_mp` (include/hassaku_hip.h)."""
+class HskBprmfShard(ctypes.Structure):
+    """Mirror of `struct hsk_bprmf_shard` (include/hassaku_hip.h)."""
     _fields_ = [
         ('base', HskBprmfState),
         ('world', c_int32), ('rank', c_int32),
-        ('n_users_global', c_int64), ('capacity', c_int64),
-        ('req_send', c_void_p), ('req_recv', c_void_p),
-        ('rows_send', c_void_p), ('rows_recv', c_void_p),
-        ('grads_send', c_void_p), ('grads_recv', c_void_p),
-        ('g_item_emb', c_void_p), ('g_item_bias', c_void_p),
-        ('slot_of_b', c_void_p),
-        ('cur_batch', c_int64), ('cur_cols', c_int64), ('users_applied', c_int64),
+        ('n_users_global', c_int64), ('n_items_global', c_int64),
+        ('item_lo', c_int64), ('capacity', c_int64), ('entry_cap', c_int64),
+        ('shard_ws', c_void_p), ('shard_ws_bytes', c_int64),
+        ('rows_send', c_void_p), ('rows_all', c_void_p),
+        ('dU_all', c_void_p), ('grads_mine', c_void_p),
+        ('s0', c_void_p), ('gsum', c_void_p),
+        ('cur_batch', c_int64), ('cur_cols', c_int64),
+        ('cur_set', c_int32), ('phase', c_int32),
     ]
 
 
@@ -87,13 +88,18 @@ SIGNATURES = {
     'hsk_aux_create': (c_void_p, []),
     'hsk_aux_destroy': (None, [c_void_p]),
     'hsk_bprmf_hint_next': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
-    'hsk_mp_prep': (c_int, [POINTER(HskBprmfMp), c_void_p, c_int64, c_int64, c_int64, c_void_p]),
-    'hsk_mp_sort': (c_int, [POINTER(HskBprmfMp), c_void_p]),
-    'hsk_mp_forward': (c_int, [POINTER(HskBprmfMp), c_void_p]),
-    'hsk_mp_item_grad': (c_int, [POINTER(HskBprmfMp), c_void_p]),
-    'hsk_mp_apply_users': (c_int, [POINTER(HskBprmfMp), c_void_p]),
-    'hsk_mp_apply_items': (c_int, [POINTER(HskBprmfMp), c_void_p]),
-    'hsk_mp_flush': (c_int, [POINTER(HskBprmfMp), c_void_p]),
+    'hsk_shard_workspace_bytes': (c_int64, [c_int64] * 4),
+    'hsk_shard_init': (c_int, [POINTER(HskBprmfShard), c_void_p]),
+    'hsk_shard_prepare': (c_int, [POINTER(HskBprmfShard), c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p]),
+    'hsk_shard_discard': (c_int, [POINTER(HskBprmfShard), c_int32, c_void_p]),
+    'hsk_shard_pack': (c_int, [POINTER(HskBprmfShard), c_int64, c_int64, c_int32, c_void_p]),
+    'hsk_shard_pos_scores': (c_int, [POINTER(HskBprmfShard), c_void_p]),
+    'hsk_shard_forward': (c_int, [POINTER(HskBprmfShard), c_void_p]),
+    'hsk_shard_pos_fix': (c_int, [POINTER(HskBprmfShard), c_void_p]),
+    'hsk_shard_apply_items': (c_int, [POINTER(HskBprmfShard), c_void_p]),
+    'hsk_shard_apply_users': (c_int, [POINTER(HskBprmfShard), c_void_p]),
+    'hsk_shard_flush': (c_int, [POINTER(HskBprmfShard), c_void_p]),
+    'hsk_shard_last_batch': (c_int, [POINTER(HskBprmfShard), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'hsk_bprmf_flush': (c_int, [POINTER(HskBprmfState), c_void_p]),
     'hsk_bprmf_last_batch': (c_int, [POINTER(HskBprmfState), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'hsk_mf_eval_topk': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,

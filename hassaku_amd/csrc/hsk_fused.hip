@@ -448,7 +448,9 @@ static int hsk_launch_prep_sample(const hsk_bprmf_state* st, const hsk_ws& w, co
 }
 
 // item sort of the entries in w.it32 -> w.perm / w.offsets
-static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t total, hipStream_t stream) {
+// n_dev: optional device-side entry count (<= total, see hsk_sort_count)
+static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t total, hipStream_t stream,
+                           const int* n_dev = nullptr) {
   const int I = (int)st->n_items;
   if (total <= 1024 * 8) {
     // one workgroup sorts the whole batch (see k_sort_small)
@@ -458,11 +460,11 @@ static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t t
     int* tn = st->lazy_items ? w.n_touched : nullptr;
     HSK_STAGE(HSK_STAGE_SCATTER, {
       if (total <= 1024 * 2)
-        k_sort_small<2><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn);
+        k_sort_small<2><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn, n_dev);
       else if (total <= 1024 * 4)
-        k_sort_small<4><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn);
+        k_sort_small<4><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn, n_dev);
       else
-        k_sort_small<8><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn);
+        k_sort_small<8><<<1, 1024, 0, stream>>>(w.it32, (int)total, I, nbits, w.perm, w.offsets, tl, tn, n_dev);
     });
     HSK_LAUNCH_CHECK();
     return HSK_OK;
@@ -474,16 +476,16 @@ static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t t
     HSK_HIP(hipFuncSetAttribute((const void*)k_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds));
   if (st->lazy_items) HSK_HIP(hipMemsetAsync(w.n_touched, 0, sizeof(int), stream));
   HSK_STAGE(HSK_STAGE_SCAN, {
-    k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist);
+    k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist, n_dev);
     k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
   });
   HSK_LAUNCH_CHECK();
   HSK_STAGE(HSK_STAGE_SCATTER, {
     k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist, w.btot,
-                                                                                 w.perm1, w.bstart);
+                                                                                 w.perm1, w.bstart, n_dev);
     k_sort_bucket<<<(unsigned)plan.n_buckets, 256, bucket_lds, stream>>>(
         w.perm1, (int)total, I, plan, w.bstart, w.perm, w.offsets, st->lazy_items ? w.touched : nullptr,
-        st->lazy_items ? w.n_touched : nullptr);
+        st->lazy_items ? w.n_touched : nullptr, n_dev);
   });
   HSK_LAUNCH_CHECK();
   return HSK_OK;
@@ -826,6 +828,6 @@ extern "C" int hsk_sample_negatives_uniform(const int64_t* csr_indptr, const int
   return HSK_OK;
 }
 
-// multi-GPU phases (row-sharded user tables)
+// multi-GPU phases (item table range-sharded, user table row-sharded)
 #include <algorithm>
-#include "hsk_mp.inc"
+#include "hsk_shard.inc"

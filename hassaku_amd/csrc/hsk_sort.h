@@ -82,9 +82,16 @@ __device__ __forceinline__ int hsk_wave_incl_scan(int v, int lane) {
   return v;
 }
 
+// n_dev (optional, every sort kernel): the actual entry count lives in device memory (item-sharded step: how many
+// of the drawn negatives a rank owns is only known on the device); n_entries is then the host-side capacity
+__device__ __forceinline__ int hsk_sort_count(int n_entries, const int* __restrict__ n_dev) {
+  return n_dev ? min(n_entries, *n_dev) : n_entries;
+}
+
 __global__ __launch_bounds__(256) void k_sort_hist(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
-                                                   int* __restrict__ hist) {
+                                                   int* __restrict__ hist, const int* __restrict__ n_dev = nullptr) {
   __shared__ int cnt[4][HSK_SORT_MAX_BUCKETS];
+  n_entries = hsk_sort_count(n_entries, n_dev);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int unit = blockIdx.x * 4 + w;
   for (int d = lane; d < p.n_buckets; d += 64) cnt[w][d] = 0;
@@ -150,7 +157,9 @@ __device__ __forceinline__ void hsk_bucket_starts(const int* __restrict__ btot, 
 
 __global__ __launch_bounds__(256) void k_sort_scatter(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
                                                       const int* __restrict__ hist, const int* __restrict__ btot,
-                                                      int2* __restrict__ perm1, int* __restrict__ bstart) {
+                                                      int2* __restrict__ perm1, int* __restrict__ bstart,
+                                                      const int* __restrict__ n_dev = nullptr) {
+  n_entries = hsk_sort_count(n_entries, n_dev);
   __shared__ int run[4][HSK_SORT_MAX_BUCKETS];
   __shared__ int bs[HSK_SORT_MAX_BUCKETS + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -190,7 +199,9 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
                                                      hsk_sort_plan p, const int* __restrict__ bstart,
                                                      int* __restrict__ perm, int* __restrict__ offsets,
                                                      int* __restrict__ touched = nullptr,
-                                                     int* __restrict__ n_touched = nullptr) {
+                                                     int* __restrict__ n_touched = nullptr,
+                                                     const int* __restrict__ n_dev = nullptr) {
+  n_entries = hsk_sort_count(n_entries, n_dev);
   // touched / n_touched (optional): compact list of the items that have entries, any order (lazy item AdamW:
   // hsk_fused.hip); needs ipb + 2 more ints of dynamic LDS
   extern __shared__ int lds[];  // cnt[4][ipb] then tot[ipb] [then list[ipb], count, base]
@@ -292,7 +303,9 @@ template <int IPT>
 __global__ __launch_bounds__(1024) void k_sort_small(const int* __restrict__ it32, int n_entries, int n_items,
                                                      int nbits, int* __restrict__ perm, int* __restrict__ offsets,
                                                      int* __restrict__ touched = nullptr,
-                                                     int* __restrict__ n_touched = nullptr) {
+                                                     int* __restrict__ n_touched = nullptr,
+                                                     const int* __restrict__ n_dev = nullptr) {
+  n_entries = hsk_sort_count(n_entries, n_dev);
   using sort_t = rocprim::block_radix_sort<unsigned int, 1024, IPT, int>;
   __shared__ typename sort_t::storage_type storage;
   const int tid = threadIdx.x;

@@ -1,35 +1,42 @@
 """Multi-GPU BPR-MF: one process per GPU, RCCL over xGMI through torch.distributed (backend "nccl").
 
-Replaces the reference's single-process nn.DataParallel (train/trainer.py:38-41).  Layout:
+Replaces the reference's single-process nn.DataParallel (train/trainer.py:38-41).  Nothing is replicated:
 
-  * user tables ROW-SHARDED: rank r owns users u with u % world == r at local row u // world (parameters,
-    AdamW moments, lazy-update bookkeeping all live only on the owner);
-  * item table REPLICATED (every item row is touched every step at the BASELINE shapes, so each rank applies the
-    same all-reduced dense item gradient);
-  * the global batch of world*B positives is cut into contiguous slices, the sampler's RNG is keyed by the global
-    batch position, so N GPUs compute the step one GPU would compute on the same world*B batch.
+  * ITEM table RANGE-SHARDED: rank r owns items [item_range(I, r, W)) with their AdamW moments and bias; an item row
+    never leaves its owner, neither does its gradient;
+  * USER table ROW-SHARDED: rank r owns users u with u % W == r at local row u // W (parameters, moments, the lazy
+    AdamW bookkeeping);
+  * a step processes a GLOBAL batch of W*B positives (weak scaling: B per GPU).  Every rank draws the same Philox
+    stream of negatives for the whole global batch and keeps the (positive, item) entries whose item it owns --
+    exactly the samples one GPU would draw for a batch of W*B -- so each rank gathers ~B*(1+N) item rows, like one
+    GPU on its own batch.
 
-Per step and rank: all_to_all 4*D*C*world B (user rows to the requesters; the requests themselves are recomputed
-by the owner, every rank knows every slice of the global batch), all_to_all 4*D*C*world B (user-row gradients back
-to the owners), all_reduce 4*(D+1)*I B (item gradient); C = per-pair slot capacity ~ B/world + 6 sigma.  Each
-collective is issued asynchronously and has independent kernels running under it: the item sort under the row
-exchange, the item-gradient pass under the gradient-row exchange, the user update under the all_reduce.  xGMI is a
-point-to-point mesh: the all_to_alls use every link at once; the all_reduce is the bandwidth term (21.9 MB at
-I=10 677, D=512).
+Per step and rank (C = user slots per owner ~ B + 6 sigma, G = W*B):
+    all_gather      user rows    [C, D] -> [W*C, D]   4*D*C bytes to every peer     (owner -> everyone)
+    all_reduce      s0           [G]                  positive scores, computed by the positive item's owner
+    all_reduce      gsum         [G]                  per positive: sum of its negatives' weights over the ranks
+    reduce_scatter  user grads   [W*C, D] -> [C, D]   4*D*C bytes to every peer     (everyone -> owner)
+The all_gather runs under the preparation (sampling, routing, item sort) of the NEXT batch, which is issued a step
+ahead on a side stream; the reduce_scatter runs under the local item-gradient pass + item AdamW.  xGMI is a
+point-to-point mesh: all_gather / reduce_scatter use all 7 links of a GPU at once (4*D*C bytes per link).
 
-Evaluation shards the USERS the same way (each rank scores the users it owns against the replicated item
-table; per-group metric sums and counts are all-reduced), which needs no table exchange at all.
+Evaluation is ITEM-SHARDED the same way (BASELINE configs[3]): per chunk of users the owners all_gather the chunk's
+user rows, every rank scores them against its item shard and keeps a local top-k, the (value, id) candidates go to
+the rank that merges that user (all_to_all, k*8 bytes per user and rank), metrics are computed there and the per-group
+sums are all-reduced at the end.  `gather_item_table()` is the other route the north star names (all_gather of the
+item shards: I*D*4 bytes), used for model.pth.
 """
 import ctypes
 import math
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from hassaku_amd import _lib, hip_ops
-from hassaku_amd._lib import HskBprmfMp
-from hassaku_amd.hip_ops import ADAM_BETA1, ADAM_BETA2, ADAM_EPS, _chk, _p, _stream
+from hassaku_amd._lib import HskBprmfShard
+from hassaku_amd.hip_ops import ADAM_BETA1, ADAM_BETA2, _chk, _p, _stream
 
 
 class _Done:
@@ -40,10 +47,10 @@ class _Done:
 
 
 class Comm:
-    """The collectives the sharded step needs, on device tensors.  With backend nccl (= RCCL on ROCm) they run on
-    the GPU directly -- `async_op=True` returns the torch Work handle, the collective then runs on RCCL's own stream
-    behind everything already queued on the current stream, and `handle.wait()` makes the current stream wait for
-    it: kernels launched in between overlap the exchange.  Any other backend (gloo in the tests) is staged through
+    """The collectives of the sharded step / evaluation on device tensors.  Backend nccl (= RCCL on ROCm): they run
+    on the GPU directly -- `async_op=True` returns the torch Work handle, the collective then runs on RCCL's own
+    stream behind everything already queued on the current stream, and `handle.wait()` makes the current stream wait
+    for it: kernels launched in between overlap the exchange.  Any other backend (gloo in the tests) is staged through
     host memory, synchronously; the handle is then already complete."""
 
     def __init__(self, group=None):
@@ -54,34 +61,56 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.native = dist.get_backend(group) == 'nccl'
 
-    def all_reduce(self, t: torch.Tensor, async_op: bool = False):
-        if self.native:
-            work = dist.all_reduce(t, group=self.group, async_op=async_op)
+    def _staged(self, t):
+        return t.is_cuda and not self.native
+
+    def all_reduce(self, t: torch.Tensor, async_op: bool = False, op: str = 'sum'):
+        rop = dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM
+        if not self._staged(t):
+            work = dist.all_reduce(t, op=rop, group=self.group, async_op=async_op)
             return work if async_op else None
-        if not t.is_cuda:
-            dist.all_reduce(t, group=self.group)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, group=self.group)
-            t.copy_(h)
+        h = t.cpu()
+        dist.all_reduce(h, op=rop, group=self.group)
+        t.copy_(h)
+        return _Done() if async_op else None
+
+    def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out [W*n, ...] = concatenation over the ranks of inp [n, ...]."""
+        if not self._staged(inp):
+            work = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
+            return work if async_op else None
+        h = inp.cpu()
+        parts = [torch.empty_like(h) for _ in range(self.world)]
+        dist.all_gather(parts, h, group=self.group)
+        out.copy_(torch.cat(parts, dim=0).view(out.shape))
+        return _Done() if async_op else None
+
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out [n, ...] = sum over the ranks of their inp[rank*n:(rank+1)*n]."""
+        if not self._staged(inp):
+            work = dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=async_op)
+            return work if async_op else None
+        h = inp.cpu()
+        dist.all_reduce(h, group=self.group)
+        n = out.shape[0]
+        out.copy_(h[self.rank * n:(self.rank + 1) * n])
         return _Done() if async_op else None
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         """Equal splits along dim 0: out[j*n:(j+1)*n] on rank i = inp[i*n:(i+1)*n] of rank j."""
-        if self.native:
+        if not self._staged(inp):
             work = dist.all_to_all_single(out, inp, group=self.group, async_op=async_op)
             return work if async_op else None
         h = inp.cpu()
         parts = [torch.empty_like(h) for _ in range(self.world)]
         dist.all_gather(parts, h, group=self.group)
         n = h.shape[0] // self.world
-        res = torch.cat([p[self.rank * n:(self.rank + 1) * n] for p in parts], dim=0)
-        out.copy_(res)
+        out.copy_(torch.cat([p[self.rank * n:(self.rank + 1) * n] for p in parts], dim=0))
         return _Done() if async_op else None
 
     def all_gather(self, inp: torch.Tensor):
         """-> list of world tensors shaped like inp."""
-        if self.native or not inp.is_cuda:
+        if not self._staged(inp):
             parts = [torch.empty_like(inp) for _ in range(self.world)]
             dist.all_gather(parts, inp, group=self.group)
             return parts
@@ -91,7 +120,7 @@ class Comm:
         return [p.to(inp.device) for p in parts]
 
     def broadcast(self, t: torch.Tensor, src: int = 0):
-        if self.native or not t.is_cuda:
+        if not self._staged(t):
             dist.broadcast(t, src=src, group=self.group)
         else:
             h = t.cpu()
@@ -102,6 +131,9 @@ class Comm:
         dist.barrier(group=self.group)
 
 
+# ------------------------------------------------------------------------------------------------
+# ownership
+# ------------------------------------------------------------------------------------------------
 def owner_of(u, world: int):
     """(owning rank, local row) of global user id(s) u."""
     return u % world, u // world
@@ -111,64 +143,78 @@ def local_user_count(n_users: int, rank: int, world: int) -> int:
     return (n_users - rank + world - 1) // world
 
 
-def pair_capacity(batch: int, world: int) -> int:
-    """Slots per (source, destination) rank pair: mean + 6 sigma of a Binomial(batch, 1/world), + slack."""
-    mean = batch / world
-    c = int(math.ceil(mean + 6.0 * math.sqrt(mean * (1.0 - 1.0 / world)) + 8))
-    return min(batch, (c + 3) // 4 * 4)
+def item_range(n_items: int, rank: int, world: int):
+    """[lo, hi) of the item ids rank owns (contiguous ranges, sizes differ by at most one)."""
+    return (n_items * rank) // world, (n_items * (rank + 1)) // world
+
+
+def user_capacity(owner_share: float, global_batch: int) -> int:
+    """User slots per owner rank: mean + 6 sigma of Binomial(global_batch, p) + slack, where p = the largest
+    share of the training interactions any rank's users hold (a batch draws its positives from the interactions,
+    so heavy users count with their weight)."""
+    mean = global_batch * owner_share
+    c = int(math.ceil(mean + 6.0 * math.sqrt(max(mean * (1.0 - owner_share), 0.0)) + 8))
+    return min(global_batch, (c + 3) // 4 * 4)
+
+
+def entry_capacity(keep_prob: float, global_batch: int, n_neg: int) -> int:
+    """Kept (positive, item) entries per rank and step: the G*N negatives fall into this rank's item range with
+    probability keep_prob each (mean + 8 sigma), plus at most G positives."""
+    mean = global_batch * n_neg * min(1.0, keep_prob)
+    c = int(math.ceil(mean + 8.0 * math.sqrt(mean) + 64)) + global_batch
+    return min(global_batch * (n_neg + 1), (c + 3) // 4 * 4)
 
 
 class ShardedBprMf:
-    """Fused BPR-MF AdamW step over `comm.world` GPUs.  Construct with the FULL user table (identical on every
-    rank, e.g. from the seeded model init); the local shard is cut out here."""
+    """Fused BPR-MF AdamW step over `comm.world` GPUs (world == 1 is allowed: same code path, collectives degenerate).
+
+    Construct with the FULL tables (identical on every rank, e.g. from the seeded model init) -- the local shards are
+    cut out here and the full tensors are not referenced afterwards -- or, with `inputs_are_shards=True`, with this
+    rank's shards directly (user rows rank::world, item rows item_range(...)) plus `n_users` / `n_items`."""
 
     def __init__(self, comm: Comm, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  batch, n_neg, csr_indptr, csr_indices, coo_user, coo_item, seed=0, beta1=ADAM_BETA1,
-                 beta2=ADAM_BETA2, eps=None, capacity: Optional[int] = None, loss='bpr', log_adjust=0.0, alias=None,
-                 optimizer='adamw'):
+                 beta2=ADAM_BETA2, eps=None, capacity: Optional[int] = None, entry_cap: Optional[int] = None,
+                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto', prefetch=True,
+                 inputs_are_shards=False, n_users: Optional[int] = None, n_items: Optional[int] = None):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.comm = comm
         W, r = comm.world, comm.rank
-        if W < 2:
-            raise ValueError('ShardedBprMf needs world >= 2 (use BprMfFusedState on one GPU)')
-        U, D = user_emb.shape
-        I = item_emb.shape[0]
+        if loss != 'bpr':
+            raise ValueError(f"the sharded step implements the bpr loss (got {loss!r}); other losses train on one GPU")
         dev = user_emb.device
+        D = user_emb.shape[1]
+        if inputs_are_shards:
+            if n_users is None or n_items is None:
+                raise ValueError('inputs_are_shards=True needs n_users and n_items (the global sizes)')
+            U, I = int(n_users), int(n_items)
+        else:
+            U, I = user_emb.shape[0], item_emb.shape[0]
+        lo, hi = item_range(I, r, W)
+        if hi <= lo:
+            raise ValueError(f'rank {r} of {W} would own no items (n_items = {I})')
         self.device, self.n_users_global, self.n_items, self.dim = dev, U, I, D
+        self.item_lo, self.item_hi = lo, hi
         self.batch, self.n_neg = int(batch), int(n_neg)
-        self.capacity = C = int(capacity or pair_capacity(self.batch, W))
-        # the replicated tables must start bit-identical on every rank: rank 0's copy wins
-        for t in (item_emb, item_bias, global_bias):
-            if t is not None:
-                comm.broadcast(t, src=0)
-        # local shards (own storage: the full table is not referenced afterwards)
-        self.user_emb = user_emb[r::W].contiguous()
-        self.user_bias = None if user_bias is None else user_bias.reshape(-1)[r::W].contiguous()
-        self.item_emb, self.item_bias, self.global_bias = item_emb, item_bias, global_bias
-        U_loc = self.user_emb.shape[0]
-        assert U_loc == local_user_count(U, r, W)
-        self.params = dict(user_emb=self.user_emb, item_emb=item_emb, item_bias=item_bias, user_bias=self.user_bias,
-                           global_bias=global_bias)
-        self.m = {k: (torch.zeros_like(t) if t is not None else None) for k, t in self.params.items()}
-        self.v = {k: (torch.zeros_like(t) if t is not None else None) for k, t in self.params.items()}
-        self.loss_out = torch.zeros(2, dtype=torch.float64, device=dev)
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
-        R = W * C
-        max_batch, max_cols = max(self.batch, R), self.n_neg + 1
-        nbytes = self.lib.hsk_bprmf_workspace_bytes(U_loc, I, D, max_batch, max_cols)
-        if nbytes <= 0:
-            raise ValueError('invalid workspace request')
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        self.req_send = torch.empty(R, dtype=torch.int32, device=dev)
-        self.req_recv = torch.full((R,), -1, dtype=torch.int32, device=dev)
-        self.rows_send = torch.zeros((R, D), dtype=torch.float32, device=dev)
-        self.rows_recv = torch.zeros((R, D), dtype=torch.float32, device=dev)
-        self.grads_send = torch.zeros((R, D), dtype=torch.float32, device=dev)
-        self.grads_recv = torch.zeros((R, D), dtype=torch.float32, device=dev)
-        # item gradient + item-bias gradient in ONE buffer -> one all_reduce
-        self.g_item = torch.zeros(I * D + I, dtype=torch.float32, device=dev)
-        self.slot_of_b = torch.zeros(self.batch, dtype=torch.int32, device=dev)
+        G, K = W * self.batch, self.n_neg + 1
+        if inputs_are_shards:
+            self.user_emb, self.item_emb = user_emb, item_emb
+            self.user_bias = None if user_bias is None else user_bias.reshape(-1)
+            self.item_bias = None if item_bias is None else item_bias.reshape(-1)
+        else:
+            # every rank must start from bit-identical tables: rank 0's copy wins
+            for t in (user_emb, item_emb, item_bias, user_bias, global_bias):
+                if t is not None and W > 1:
+                    comm.broadcast(t, src=0)
+            self.user_emb = user_emb[r::W].contiguous()
+            self.user_bias = None if user_bias is None else user_bias.reshape(-1)[r::W].contiguous()
+            self.item_emb = item_emb[lo:hi].contiguous()
+            self.item_bias = None if item_bias is None else item_bias.reshape(-1)[lo:hi].contiguous()
+        self.global_bias = global_bias
+        U_loc, I_loc = self.user_emb.shape[0], hi - lo
+        if U_loc != local_user_count(U, r, W) or self.item_emb.shape[0] != I_loc:
+            raise ValueError('shard shapes do not match the ownership rule')
         for t, name in ((csr_indptr, 'csr_indptr'), (coo_user, 'coo_user'), (coo_item, 'coo_item')):
             if t is None:
                 raise ValueError(f'{name} is required')
@@ -177,81 +223,175 @@ class ShardedBprMf:
         _chk(coo_user, torch.int32, 'coo_user')
         _chk(coo_item, torch.int32, 'coo_item', tuple(coo_user.shape))
         self._keep = (csr_indptr, csr_indices, coo_user, coo_item)
+        nnz = coo_user.numel()
 
-        mp = HskBprmfMp()
-        st = mp.base
+        # capacities from the data: the share of the interactions the busiest owner holds, and the probability
+        # that a drawn negative falls into this rank's item range (interaction-weighted over the users)
+        if capacity is None:
+            share = torch.bincount(coo_user.long() % W, minlength=W).double().max().item() / max(nnz, 1)
+            capacity = user_capacity(max(share, 1.0 / W), G)
+        if entry_cap is None:
+            deg = (csr_indptr[1:] - csr_indptr[:-1]).double()
+            inv_free = float((deg / (I - deg).clamp(min=1.0)).sum().item()) / max(float(deg.sum().item()), 1.0)
+            keep = I_loc * inv_free
+            if alias is not None:     # 'popular' sampling: mass of the item law inside the range, with headroom
+                prob, idx = alias[0].double(), alias[1].long()
+                mass = torch.zeros(I, dtype=torch.float64, device=dev).index_add_(0, idx, 1.0 - prob) + prob
+                keep = min(1.0, 1.5 * float(mass[lo:hi].sum().item()) / I + 0.02)
+            entry_cap = entry_capacity(keep, G, self.n_neg)
+        C, cap = int(min(capacity, G)), int(min(entry_cap, G * K))
+        if W > 1:   # the all_gather / reduce_scatter need one C on every rank
+            agreed = torch.tensor([C], dtype=torch.int64, device=dev)
+            comm.all_reduce(agreed, op='max')
+            C = int(agreed.item())
+        self.capacity, self.entry_cap = C, cap
+        self.params = dict(user_emb=self.user_emb, item_emb=self.item_emb, item_bias=self.item_bias,
+                           user_bias=self.user_bias, global_bias=global_bias)
+        self.m = {k: (torch.zeros_like(t) if t is not None else None) for k, t in self.params.items()}
+        self.v = {k: (torch.zeros_like(t) if t is not None else None) for k, t in self.params.items()}
+        self.loss_out = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        max_batch, max_cols = max(G, C), K
+        nbytes = self.lib.hsk_bprmf_workspace_bytes(U_loc, I_loc, D, max_batch, max_cols)
+        sbytes = self.lib.hsk_shard_workspace_bytes(max_batch, max_cols, C, cap)
+        if nbytes <= 0 or sbytes <= 0:
+            raise ValueError('invalid workspace request')
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.shard_ws = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        self.rows_send = torch.zeros((C, D), dtype=torch.float32, device=dev)
+        self.rows_all = torch.zeros((W * C, D), dtype=torch.float32, device=dev)
+        self.dU_all = torch.zeros((W * C, D), dtype=torch.float32, device=dev)
+        self.grads_mine = torch.zeros((C, D), dtype=torch.float32, device=dev)
+        self.s0 = torch.zeros(G, dtype=torch.float32, device=dev)
+        self.gsum = torch.zeros(G, dtype=torch.float32, device=dev)
+
+        sh = HskBprmfShard()
+        st = sh.base
         for k, t in self.params.items():
             setattr(st, k, _p(t))
             setattr(st, 'm_' + k, _p(self.m[k]))
             setattr(st, 'v_' + k, _p(self.v[k]))
-        st.n_users, st.n_items, st.dim = U_loc, I, D
+        st.n_users, st.n_items, st.dim = U_loc, I_loc, D
         st.lr, st.beta1, st.beta2, st.eps, st.wd = lr, beta1, beta2, hip_ops.opt_eps(optimizer, eps), wd
         st.opt_kind = hip_ops.OPT_KINDS[optimizer]
         st.step = 0
         st.csr_indptr, st.csr_indices = _p(csr_indptr), _p(csr_indices)
-        st.coo_user, st.coo_item, st.nnz = _p(coo_user), _p(coo_item), coo_user.numel()
+        st.coo_user, st.coo_item, st.nnz = _p(coo_user), _p(coo_item), nnz
         st.seed = seed & 0xFFFFFFFFFFFFFFFF
         st.workspace, st.workspace_bytes = _p(self.workspace), nbytes
         st.max_batch, st.max_cols = max_batch, max_cols
         st.lazy_users = 1
+        if lazy_items == 'auto':   # worth it when most of the shard's rows are outside every batch
+            lazy_items = D % 2 == 0 and I_loc >= 2 * cap
+        st.lazy_items = 1 if lazy_items else 0
         st.timing_mask, st.timing, st.aux, st.timing_every, st.timing_now = 0, None, None, 1, 0
-        if loss == 'bce' and (user_bias is not None or global_bias is not None):
-            raise ValueError('the fused bce step treats user/global bias as gradient-free')
         st.loss_kind, st.ssm_log_adjust = hip_ops.LOSS_KINDS[loss], float(log_adjust)
         self.alias = alias
         st.alias_prob, st.alias_idx = (None, None) if alias is None else (_p(alias[0]), _p(alias[1]))
         st.loss_out, st.status = _p(self.loss_out), _p(self.status)
-        mp.world, mp.rank = W, r
-        mp.n_users_global, mp.capacity = U, C
-        mp.req_send, mp.req_recv = _p(self.req_send), _p(self.req_recv)
-        mp.rows_send, mp.rows_recv = _p(self.rows_send), _p(self.rows_recv)
-        mp.grads_send, mp.grads_recv = _p(self.grads_send), _p(self.grads_recv)
-        mp.g_item_emb = _p(self.g_item)
-        mp.g_item_bias = (self.g_item.data_ptr() + 4 * I * D) if item_bias is not None else None
-        mp.slot_of_b = _p(self.slot_of_b)
-        mp.cur_batch = mp.cur_cols = mp.users_applied = 0
-        self.mp = mp
-        _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(mp.base), _stream()), 'hsk_bprmf_init_workspace')
+        sh.world, sh.rank = W, r
+        sh.n_users_global, sh.n_items_global, sh.item_lo = U, I, lo
+        sh.capacity, sh.entry_cap = C, cap
+        sh.shard_ws, sh.shard_ws_bytes = _p(self.shard_ws), sbytes
+        sh.rows_send, sh.rows_all = _p(self.rows_send), _p(self.rows_all)
+        sh.dU_all, sh.grads_mine = _p(self.dU_all), _p(self.grads_mine)
+        sh.s0, sh.gsum = _p(self.s0), _p(self.gsum)
+        self.sh = sh
+        _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(sh.base), _stream()), 'hsk_bprmf_init_workspace')
+        _lib.check(self.lib.hsk_shard_init(ctypes.byref(sh), _stream()), 'hsk_shard_init')
+        # the next batch is prepared a step ahead on a side stream (device-side counterpart of DataLoader prefetch)
+        self._side = torch.cuda.Stream(device=dev) if prefetch else None
+        self._ev_fork, self._ev_ready = torch.cuda.Event(), torch.cuda.Event()
+        self._cur_set = 0
+        self._pf = None          # (order ptr, start, batch, step index it is for, set, order tensor kept alive)
 
     @property
     def step_count(self) -> int:
-        return int(self.mp.base.step)
+        return int(self.sh.base.step)
 
-    def step_sampled(self, order: Optional[torch.Tensor], start_global: int, batch: Optional[int] = None):
-        """One global step: positives = interactions order[start_global : start_global + world*batch]."""
-        lib, mp, comm = self.lib, self.mp, self.comm
+    # -- one global step -------------------------------------------------------------------------------------
+    def _prepare(self, order, start_global, nb, set_, stream):
+        _lib.check(self.lib.hsk_shard_prepare(ctypes.byref(self.sh), _p(order), start_global, nb, self.n_neg, set_,
+                                              stream), 'hsk_shard_prepare')
+
+    def step_sampled(self, order: Optional[torch.Tensor], start_global: int, batch: Optional[int] = None,
+                     next_start: Optional[int] = None, next_batch: Optional[int] = None):
+        """One global step: positives = interactions order[start_global : start_global + world*batch].
+        `next_start` (and `next_batch`) name the batch of the FOLLOWING call: it is sampled, routed and item-sorted on
+        the side stream while this step's exchanges run (results are identical with or without it)."""
+        lib, sh, comm = self.lib, self.sh, self.comm
         nb = self.batch if batch is None else int(batch)
+        G = comm.world * nb
+        if nb > self.batch:
+            raise ValueError(f'batch {nb} above the batch {self.batch} the state was built for')
         if order is not None:
             _chk(order, torch.int64, 'order')
-            if start_global + comm.world * nb > order.numel():
+            if start_global + G > order.numel():
                 raise ValueError('order too short for the global batch')
-        s = _stream()
-        ref = ctypes.byref(mp)
-        # sample + route (own requests and, recomputed locally, the incoming ones) + owner catch-up + pack
-        _lib.check(lib.hsk_mp_prep(ref, _p(order), start_global, nb, self.n_neg, s), 'hsk_mp_prep')
-        rows = comm.all_to_all(self.rows_recv, self.rows_send, async_op=True)
-        _lib.check(lib.hsk_mp_sort(ref, s), 'hsk_mp_sort')                    # under the row exchange
+        main = torch.cuda.current_stream()
+        s = main.cuda_stream
+        ref = ctypes.byref(sh)
+        key = (_p(order), int(start_global), nb, self.step_count)
+        if self._pf is not None and self._pf[:4] == key:
+            main.wait_event(self._ev_ready)              # sampled + sorted during the previous step
+            set_ = self._pf[4]
+            self._pf = None
+        else:
+            self._discard_prefetch()
+            set_ = self._cur_set ^ 1
+            self._prepare(order, start_global, nb, set_, s)
+        self._cur_set = set_
+        _lib.check(lib.hsk_shard_pack(ref, nb, self.n_neg, set_, s), 'hsk_shard_pack')
+        rows = comm.all_gather_into(self.rows_all, self.rows_send, async_op=True)
+        if self._side is not None and next_start is not None:
+            nnb = nb if next_batch is None else int(next_batch)
+            self._ev_fork.record(main)
+            self._side.wait_event(self._ev_fork)
+            self._prepare(order, int(next_start), nnb, set_ ^ 1, self._side.cuda_stream)
+            self._ev_ready.record(self._side)
+            self._pf = (_p(order), int(next_start), nnb, self.step_count + 1, set_ ^ 1, order)
         rows.wait()
-        _lib.check(lib.hsk_mp_forward(ref, s), 'hsk_mp_forward')
-        grads = comm.all_to_all(self.grads_recv, self.grads_send, async_op=True)
-        _lib.check(lib.hsk_mp_item_grad(ref, s), 'hsk_mp_item_grad')          # under the gradient-row exchange
-        items = comm.all_reduce(self.g_item, async_op=True)
+        _lib.check(lib.hsk_shard_pos_scores(ref, s), 'hsk_shard_pos_scores')
+        comm.all_reduce(self.s0[:G])
+        _lib.check(lib.hsk_shard_forward(ref, s), 'hsk_shard_forward')
+        comm.all_reduce(self.gsum[:G])
+        _lib.check(lib.hsk_shard_pos_fix(ref, s), 'hsk_shard_pos_fix')
+        grads = comm.reduce_scatter(self.grads_mine, self.dU_all, async_op=True)
+        _lib.check(lib.hsk_shard_apply_items(ref, s), 'hsk_shard_apply_items')     # under the reduce_scatter
         grads.wait()
-        _lib.check(lib.hsk_mp_apply_users(ref, s), 'hsk_mp_apply_users')      # under the item-gradient all_reduce
-        items.wait()
-        _lib.check(lib.hsk_mp_apply_items(ref, s), 'hsk_mp_apply_items')
+        _lib.check(lib.hsk_shard_apply_users(ref, s), 'hsk_shard_apply_users')
 
-    # -- per-stage device timing (same recorder as the single-GPU state; 'fwd' and 'item' are bracketed) -----
+    def _discard_prefetch(self):
+        """A prepared batch that the next call does not consume: give its owner map back."""
+        if self._pf is None:
+            return
+        torch.cuda.current_stream().wait_event(self._ev_ready)
+        _lib.check(self.lib.hsk_shard_discard(ctypes.byref(self.sh), self._pf[4], _stream()), 'hsk_shard_discard')
+        self._pf = None
+
+    def last_batch(self, batch: Optional[int] = None):
+        """(offs int32 [G+1], local item ids int32 [entry_cap] (-1 beyond the kept entries), users int32 [G]) of the
+        batch of the latest step -- debug / parity."""
+        nb = self.batch if batch is None else int(batch)
+        G = self.comm.world * nb
+        offs = torch.empty(G + 1, dtype=torch.int32, device=self.device)
+        items = torch.empty(self.entry_cap, dtype=torch.int32, device=self.device)
+        u = torch.empty(G, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsk_shard_last_batch(ctypes.byref(self.sh), self._cur_set, nb, _p(offs), _p(items), _p(u),
+                                                 _stream()), 'hsk_shard_last_batch')
+        return offs, items, u
+
+    # -- per-stage device timing (same recorder as the single-GPU state; 'fwd', 'item', 'user' are bracketed) ------
     def enable_timing(self, stages=('fwd',), every=1):
         if not getattr(self, '_timing', None):
             self._timing = self.lib.hsk_timing_create()
         names = hip_ops.BprMfFusedState.STAGES
-        self.mp.base.timing = self._timing
-        self.mp.base.timing_mask = sum(1 << names.index(s) for s in stages)
-        self.mp.base.timing_every = int(every)
+        self.sh.base.timing = self._timing
+        self.sh.base.timing_mask = sum(1 << names.index(s) for s in stages if s in ('fwd', 'item', 'user'))
+        self.sh.base.timing_every = int(every)
 
     def disable_timing(self):
-        self.mp.base.timing_mask = 0
+        self.sh.base.timing_mask = 0
 
     def collect_timing(self):
         if not getattr(self, '_timing', None):
@@ -263,7 +403,8 @@ class ShardedBprMf:
         return {s: (ms[i], cnt[i]) for i, s in enumerate(names) if cnt[i] > 0}
 
     def flush(self):
-        _lib.check(self.lib.hsk_mp_flush(ctypes.byref(self.mp), _stream()), 'hsk_mp_flush')
+        self._discard_prefetch()
+        _lib.check(self.lib.hsk_shard_flush(ctypes.byref(self.sh), _stream()), 'hsk_shard_flush')
 
     def last_loss(self) -> float:
         t = self.loss_out[:1].clone()
@@ -281,12 +422,13 @@ class ShardedBprMf:
         self.comm.all_reduce(bad)        # a flag on any rank fails every rank
         s = int(self.status.item())
         if s & 4:
-            raise RuntimeError(f'{what}: request routing overflowed capacity {self.capacity}; '
-                               f'construct ShardedBprMf with a larger `capacity`')
+            raise RuntimeError(f'{what}: a capacity was exceeded (user slots per owner {self.capacity}, kept entries '
+                               f'per rank {self.entry_cap}); construct ShardedBprMf with larger `capacity` / `entry_cap`')
         hip_ops.raise_on_status(self.status, what)
         if int(bad.item()):
             raise RuntimeError(f'{what}: another rank reported a failure')
 
+    # -- assembling the full tables (model.pth, hand-over to a single-GPU consumer) --------------------------
     def gather_user_table(self):
         """Full [U, D] user table (and [U] user bias) assembled from the shards, on every rank."""
         self.flush()
@@ -304,50 +446,115 @@ class ShardedBprMf:
 
         return gather(self.user_emb), (None if self.user_bias is None else gather(self.user_bias))
 
+    def gather_item_table(self):
+        """Full [I, D] item table (and [I] item bias): the all_gather of the item shards."""
+        self.flush()
+        W, I = self.comm.world, self.n_items
+        n_max = max(item_range(I, r, W)[1] - item_range(I, r, W)[0] for r in range(W))
 
-def evaluate_item_sharded(comm: Comm, user_emb, item_emb, item_bias, user_bias, global_bias, dataset, evaluator,
-                          chunk: int = 1024):
-    """ITEM-sharded full evaluation (BASELINE config 4): rank r scores every user against the item range it owns
-    (`hsk_mf_eval_topk` with item_begin/item_count), keeps its local top-k, the (value, id) candidate lists are
-    all-gathered (k*8 bytes per user and rank) and merged to the global top-k (`hsk_topk_merge`); metrics are then
-    computed for this rank's slice of the users and all-reduced.  Tables are passed whole (replicated) here; a rank
-    only reads its item rows, so the same code serves a table that is physically sharded by item range.
-    `user_emb` is the FULL user table (e.g. `ShardedBprMf.gather_user_table()`)."""
+        def gather(t):
+            pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[:t.shape[0]] = t
+            out = torch.empty((W * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            self.comm.all_gather_into(out, pad)
+            return torch.cat([out[r * n_max: r * n_max + item_range(I, r, W)[1] - item_range(I, r, W)[0]]
+                              for r in range(W)], dim=0)
+
+        return gather(self.item_emb), (None if self.item_bias is None else gather(self.item_bias))
+
+
+# ------------------------------------------------------------------------------------------------
+# item-sharded full evaluation (BASELINE configs[3])
+# ------------------------------------------------------------------------------------------------
+def evaluate_item_sharded(comm: Comm, sharded: ShardedBprMf, dataset, evaluator, chunk: int = 2048):
+    """Full evaluation on the sharded tables (eval/eval.py:237-253 + FullEvaluator of the reference).  Per chunk of
+    users: (1) the owners all_gather the chunk's user rows; (2) every rank scores the chunk against ITS item shard --
+    `hsk_mf_eval_topk` over the physical slice, exclusion mask restricted to its range -- and keeps a local top-k with
+    global item ids; (3) the candidates of user j go to the rank that merges j (all_to_all, k*8 bytes per user and
+    rank), which runs `hsk_topk_merge` and the rank metrics for its share of the chunk; (4) per-group sums and counts
+    are all-reduced once at the end.  The candidate exchange of a chunk runs under the scoring of the next one.
+    `dataset` is a FullEvalDataset (its CSRs are global); `evaluator` supplies K_VALUES and the user groups."""
+    sharded.flush()
     W, r = comm.world, comm.rank
-    dev = user_emb.device
+    dev = sharded.device
     arr = dataset.device_arrays(dev)
-    n_users, n_items = user_emb.shape[0], item_emb.shape[0]
-    lo_i = (n_items * r) // W
-    hi_i = (n_items * (r + 1)) // W
+    U, I, D = sharded.n_users_global, sharded.n_items, sharded.dim
+    lo_i, I_loc = sharded.item_lo, sharded.item_hi - sharded.item_lo
     ks = sorted(evaluator.K_VALUES, reverse=True)
     k = ks[0]
-    kk = min(k, hi_i - lo_i)
+    if I < k:
+        raise ValueError(f'full evaluation needs at least {k} items (K_VALUES), got {I}')
+    kk = min(k, I_loc)
     n_groups = evaluator.get_n_groups()
     groups = evaluator.get_user_to_user_group().to(dev) if n_groups > 0 else None
     sums = torch.zeros((n_groups + 1, len(ks), 3), dtype=torch.float64, device=dev)
     counts = torch.zeros(n_groups + 1, dtype=torch.float64, device=dev)
     status = hip_ops.new_status(dev)
+    chunk = max(W, (int(chunk) + W - 1) // W * W)         # chunk boundaries at multiples of W: a rank's rows of a chunk
+    S = chunk // W                                         # are a contiguous slice of its shard; S users merged per rank
+    scores = torch.empty((chunk, I_loc), dtype=torch.float32, device=dev)
+    send_u = torch.zeros((S, D), dtype=torch.float32, device=dev)
+    all_u = torch.empty((W * S, D), dtype=torch.float32, device=dev)
+    has_ub = sharded.user_bias is not None
+    send_b = torch.zeros(S, dtype=torch.float32, device=dev) if has_ub else None
+    all_b = torch.empty(W * S, dtype=torch.float32, device=dev) if has_ub else None
+    bufs = [dict(inp=torch.empty((W * S, 2 * k), dtype=torch.int32, device=dev),
+                 out=torch.empty((W * S, 2 * k), dtype=torch.int32, device=dev)) for _ in range(2)]
+    pending = None
+
+    def finish(p):
+        work, out, lo, n = p
+        work.wait()
+        c = out.view(W, S, 2 * k)
+        cand_v = c[:, :, :k].contiguous().view(torch.float32)
+        cand_i = c[:, :, k:].contiguous()
+        _, ids = hip_ops.topk_merge(cand_v, cand_i)
+        n_mine = max(0, min(S, n - r * S))                 # this rank merges users lo + r*S .. of the chunk
+        if n_mine == 0:
+            return
+        um = torch.arange(lo + r * S, lo + r * S + n_mine, device=dev)
+        met = hip_ops.rank_metrics(ids[:n_mine].contiguous(), um, arr['label_indptr'], arr['label_indices'], ks).double()
+        sums[0] += met.sum(0)
+        counts[0] += n_mine
+        for g in range(n_groups):
+            sel = groups[um] == g
+            sums[1 + g] += (met * sel.view(-1, 1, 1)).sum(0)
+            counts[1 + g] += sel.sum()
+
     with torch.no_grad():
-        for lo in range(0, n_users, chunk):
-            u = torch.arange(lo, min(lo + chunk, n_users), device=dev)
-            v, i, _ = hip_ops.mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u, kk,
-                                           arr['excl_indptr'], arr['excl_indices'], item_begin=lo_i,
-                                           item_count=hi_i - lo_i, status=status)
-            pv = torch.full((len(u), k), float('-inf'), device=dev)
-            pi = torch.full((len(u), k), 2 ** 31 - 1, dtype=torch.int32, device=dev)
-            pv[:, :kk], pi[:, :kk] = v, i
-            cand_v = torch.stack(comm.all_gather(pv)).contiguous()      # [W, R, k]
-            cand_i = torch.stack(comm.all_gather(pi)).contiguous()
-            _, ids = hip_ops.topk_merge(cand_v, cand_i)
-            mine = slice(r, len(u), W)                                   # metrics: this rank's share of the chunk
-            um = u[mine].contiguous()
-            met = hip_ops.rank_metrics(ids[mine].contiguous(), um, arr['label_indptr'], arr['label_indices'], ks).double()
-            sums[0] += met.sum(0)
-            counts[0] += len(um)
-            for g in range(n_groups):
-                sel = groups[um] == g
-                sums[1 + g] += met[sel].sum(0)
-                counts[1 + g] += sel.sum()
+        for ci, lo in enumerate(range(0, U, chunk)):
+            n = min(chunk, U - lo)
+            # (1) user rows of the chunk: global user lo + j lives on rank j % W at local row (lo + j) // W
+            mine = local_user_count(n, r, W)               # users lo + r, lo + r + W, ... < lo + n
+            send_u.zero_()
+            send_u[:mine] = sharded.user_emb[lo // W: lo // W + mine]
+            comm.all_gather_into(all_u, send_u)
+            cu = all_u.view(W, S, D).transpose(0, 1).reshape(W * S, D)[:n].contiguous()
+            cb = None
+            if has_ub:
+                send_b.zero_()
+                send_b[:mine] = sharded.user_bias[lo // W: lo // W + mine]
+                comm.all_gather_into(all_b, send_b)
+                cb = all_b.view(W, S).t().reshape(W * S)[:n].contiguous()
+            # (2) local scores + top-k over the physical item shard
+            u = torch.arange(n, device=dev)
+            v, i, _ = hip_ops.mf_eval_topk(cu, sharded.item_emb, sharded.item_bias, cb, sharded.global_bias, u, kk,
+                                           arr['excl_indptr'][lo: lo + n + 1], arr['excl_indices'], item_begin=lo_i,
+                                           item_count=I_loc, scores_ws=scores, status=status, item_shard=True,
+                                           n_items_global=I)
+            b = bufs[ci & 1]
+            inp = b['inp'].view(W * S, 2, k)
+            inp[:, 0, :] = torch.tensor(float('-inf'), device=dev).view(torch.int32)
+            inp[:, 1, :] = 2 ** 31 - 1
+            inp[:n, 0, :kk] = v.view(torch.int32)
+            inp[:n, 1, :kk] = i
+            # (3) candidates to the merging rank; waited for after the next chunk has been issued
+            work = comm.all_to_all(b['out'], b['inp'], async_op=True)
+            if pending is not None:
+                finish(pending)
+            pending = (work, b['out'], lo, n)
+        if pending is not None:
+            finish(pending)
     hip_ops.raise_on_status(status, 'item-sharded eval')
     comm.all_reduce(sums)
     comm.all_reduce(counts)
@@ -355,55 +562,6 @@ def evaluate_item_sharded(comm: Comm, user_emb, item_emb, item_bias, user_bias, 
 
 
 def _metric_dict(sums, counts, ks, n_groups):
-    out = {}
-    for gi in range(n_groups + 1):
-        prefix = '' if gi == 0 else f'group_{gi - 1}_'
-        for t, k in enumerate(ks):
-            for j, name in enumerate(('precision', 'recall', 'ndcg')):
-                out[f'{prefix}{name}@{k}'] = float(sums[gi, t, j] / counts[gi])
-    return out
-
-
-def evaluate_sharded(comm: Comm, sharded: ShardedBprMf, dataset, evaluator, chunk: int = 1024):
-    """Users-sharded full evaluation: this rank scores the users it owns; sums and counts are all-reduced.
-    `dataset` is a FullEvalDataset; `evaluator` a FullEvaluator (only its K_VALUES / group map are used)."""
-    sharded.flush()
-    W, r = comm.world, comm.rank
-    dev = sharded.device
-    key = f'shard{r}of{W}:{dev}'
-    cache = dataset._device_cache
-    if key not in cache:
-        lab, exc = dataset.label_csr.subset_rows(r, W), dataset.exclude_csr.subset_rows(r, W)
-        lp, li = lab.to_device(dev)
-        ep, ei = exc.to_device(dev)
-        cache[key] = dict(label_indptr=lp, label_indices=li, excl_indptr=ep, excl_indices=ei)
-    arr = cache[key]
-    ks = sorted(evaluator.K_VALUES, reverse=True)
-    n_local = sharded.user_emb.shape[0]
-    n_groups = evaluator.get_n_groups()
-    groups = None
-    if n_groups > 0:
-        groups = evaluator.get_user_to_user_group().to(dev)[r::W]
-    sums = torch.zeros((n_groups + 1, len(ks), 3), dtype=torch.float64, device=dev)
-    counts = torch.zeros(n_groups + 1, dtype=torch.float64, device=dev)
-    status = hip_ops.new_status(dev)
-    with torch.no_grad():
-        for lo in range(0, n_local, chunk):
-            u = torch.arange(lo, min(lo + chunk, n_local), device=dev)
-            _, ids, _ = hip_ops.mf_eval_topk(sharded.user_emb, sharded.item_emb, sharded.item_bias, sharded.user_bias,
-                                             sharded.global_bias, u, ks[0], arr['excl_indptr'], arr['excl_indices'],
-                                             status=status)
-            met = hip_ops.rank_metrics(ids, u, arr['label_indptr'], arr['label_indices'], ks).double()
-            sums[0] += met.sum(0)
-            counts[0] += len(u)
-            for g in range(n_groups):
-                sel = groups[u] == g
-                sums[1 + g] += met[sel].sum(0)
-                counts[1 + g] += sel.sum()
-    hip_ops.raise_on_status(status, 'sharded eval')
-    comm.all_reduce(sums)
-    comm.all_reduce(counts)
-    sums, counts = sums.cpu(), counts.cpu()
     out = {}
     for gi in range(n_groups + 1):
         prefix = '' if gi == 0 else f'group_{gi - 1}_'

@@ -478,17 +478,27 @@ class BprMfFusedState:
 # evaluation
 # ------------------------------------------------------------------------------------------------
 def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k, excl_indptr=None, excl_indices=None,
-                 item_begin=0, item_count=None, scores_ws=None, status=None):
-    """Masked score matrix of one item shard and its top-k.  -> (vals [R,k] f32, idx [R,k] i32 global, scores)."""
+                 item_begin=0, item_count=None, scores_ws=None, status=None, item_shard=False, n_items_global=None):
+    """Masked score matrix of one item shard and its top-k.  -> (vals [R,k] f32, idx [R,k] i32 global, scores).
+    item_shard=True: `item_emb` / `item_bias` are the PHYSICAL shard (rows item_begin .. item_begin + item_count of a
+    catalogue of n_items_global items); the library is handed the virtual base of the catalogue and only ever
+    dereferences the shard's rows (include/hassaku_hip.h)."""
     _lib.require_gpu()
     lib = _lib.load()
     n_users, dim = user_emb.shape
     n_items = item_emb.shape[0]
-    if item_count is None:
+    if item_shard:
+        if item_count is None:
+            item_count = n_items
+        if item_count != n_items or n_items_global is None or item_begin + item_count > n_items_global:
+            raise ValueError('item_shard: item_emb must hold exactly rows [item_begin, item_begin + item_count)')
+    elif item_count is None:
         item_count = n_items - item_begin
     _chk(user_emb, torch.float32, 'user_emb')
     _chk(item_emb, torch.float32, 'item_emb', (n_items, dim))
     _chk(item_bias, torch.float32, 'item_bias', optional=True)
+    if item_bias is not None and item_bias.numel() != n_items:
+        raise ValueError('item_bias size mismatch')
     _chk(user_bias, torch.float32, 'user_bias', optional=True)
     _chk(global_bias, torch.float32, 'global_bias', optional=True)
     _chk(u_idx, torch.int64, 'u_idx')
@@ -505,7 +515,12 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
             raise ValueError('scores_ws too small')
     vals = torch.empty((R, k), dtype=torch.float32, device=dev)
     idx = torch.empty((R, k), dtype=torch.int32, device=dev)
-    _lib.check(lib.hsk_mf_eval_topk(_p(user_emb), _p(item_emb), _p(item_bias), _p(user_bias), _p(global_bias),
+    p_emb, p_bias = _p(item_emb), _p(item_bias)
+    if item_shard:
+        p_emb -= 4 * dim * item_begin
+        p_bias = None if p_bias is None else p_bias - 4 * item_begin
+        n_items = n_items_global
+    _lib.check(lib.hsk_mf_eval_topk(_p(user_emb), p_emb, p_bias, _p(user_bias), _p(global_bias),
                                     n_users, n_items, dim, _p(u_idx), R, item_begin, item_count,
                                     _p(excl_indptr), _p(excl_indices), k, _p(scores_ws), _p(vals), _p(idx),
                                     _p(status), _stream()), 'hsk_mf_eval_topk')

@@ -60,9 +60,10 @@ class Trainer:
         import torch.distributed as tdist
         multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
         if multi:
-            if not (fusable and isinstance(train_loader, TrainDataLoader)):
-                raise RuntimeError('multi-GPU training supports mf + {bpr, bce, sampled_softmax} + {adamw, adam, adagrad} with the '
-                                   'device TrainDataLoader (bce: without user / global bias)')
+            if not (fusable and isinstance(train_loader, TrainDataLoader)
+                    and isinstance(rec_loss, RecBayesianPersonalizedRankingLoss)):
+                raise RuntimeError('multi-GPU training supports mf + bpr + {adamw, adam, adagrad} with the device '
+                                   'TrainDataLoader (other losses train on one GPU)')
             self.sharded = self._build_sharded(conf)
             self.optimizer = None
         elif want_fused and fusable:
@@ -108,18 +109,37 @@ class Trainer:
         user_emb, item_emb, ib, ub, gb = self.model.tables()
         loader = self.train_loader
         arrays = loader.dataset.device_arrays(torch.device(self.device))
-        return ShardedBprMf(self.comm, user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd,
-                            batch=loader.batch_size, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed,
-                            loss=self.rec_loss.kind, log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0),
-                            alias=loader.interaction_sampler.alias(torch.device(self.device)),
-                            optimizer=conf['optimizer'], **arrays)
+        sh = ShardedBprMf(self.comm, user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd,
+                          batch=loader.batch_size, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed,
+                          loss=self.rec_loss.kind, log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0),
+                          alias=loader.interaction_sampler.alias(torch.device(self.device)),
+                          optimizer=conf['optimizer'], **arrays)
+        self._release_full_tables()
+        return sh
+
+    def _sharded_params(self):
+        m = self.pointer_to_model
+        out = [(m.user_embeddings.weight, 'user_emb', True), (m.item_embeddings.weight, 'item_emb', False)]
+        if m.use_user_bias:
+            out.append((m.user_bias.weight, 'user_bias', True))
+        if m.use_item_bias:
+            out.append((m.item_bias.weight, 'item_bias', False))
+        return out
+
+    def _release_full_tables(self):
+        """The shards are the parameters now: the model's full tables are dropped (they come back, gathered from the
+        shards, only while a checkpoint is written) so that no rank holds more than its share."""
+        for p, _, _ in self._sharded_params():
+            p.data = torch.empty((0,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
 
     def _sync_model_from_shards(self):
-        """Assemble the row-sharded user table into the model's parameters (every rank), e.g. before saving."""
+        """Assemble the sharded tables into the model's parameters (every rank), e.g. before saving."""
         full_u, full_ub = self.sharded.gather_user_table()
-        self.pointer_to_model.user_embeddings.weight.data.copy_(full_u)
-        if full_ub is not None:
-            self.pointer_to_model.user_bias.weight.data.copy_(full_ub.view(-1, 1))
+        full_i, full_ib = self.sharded.gather_item_table()
+        full = {'user_emb': full_u, 'item_emb': full_i, 'user_bias': None if full_ub is None else full_ub.view(-1, 1),
+                'item_bias': None if full_ib is None else full_ib.view(-1, 1)}
+        for p, name, _ in self._sharded_params():
+            p.data = full[name]
 
     def _save(self):
         if self.sharded is not None:
@@ -127,6 +147,7 @@ class Trainer:
             if self.comm.rank == 0:
                 self.pointer_to_model.save_model_to_path(self.model_path)
             self.comm.barrier()
+            self._release_full_tables()
         else:
             self.pointer_to_model.save_model_to_path(self.model_path)
 
@@ -142,9 +163,13 @@ class Trainer:
         steps, pos = 0, 0
         while n - pos >= W:
             nb = min(bs, (n - pos) // W)
-            sh.step_sampled(order, pos, nb)
-            pos += nb * W
+            nxt = pos + nb * W                      # the loader knows its next batch: prepared a step ahead
+            nnb = min(bs, (n - nxt) // W)
+            sh.step_sampled(order, pos, nb, next_start=nxt if nnb > 0 else None, next_batch=nnb)
+            pos = nxt
             steps += 1
+            if steps == 1:
+                sh.check_status()                   # a capacity that is too small shows on the first batch
         sh.flush()
         rec = sh.pop_loss_sum() / max(steps, 1)
         sh.check_status()
@@ -258,6 +283,8 @@ class Trainer:
             log_dict = {**metrics, **losses}
             self._post_val(epoch, log_dict)
             self._log(log_dict)
+        if self.sharded is not None:
+            self._sync_model_from_shards()   # the model leaves fit() with full tables, as on one GPU
         return self.best_metrics
 
     @torch.no_grad()
@@ -267,10 +294,10 @@ class Trainer:
             self.fused.flush()
         dataset = self.val_loader.dataset
         if self.sharded is not None:
-            from hassaku_amd.dist import evaluate_sharded
+            from hassaku_amd.dist import evaluate_item_sharded
             evaluator = FullEvaluator(aggr_by_group=True, n_groups=dataset.n_user_groups,
                                       user_to_user_group=dataset.user_to_user_group)
-            return evaluate_sharded(self.comm, self.sharded, dataset, evaluator)
+            return evaluate_item_sharded(self.comm, self.sharded, dataset, evaluator)
         evaluator = FullEvaluator(aggr_by_group=True, n_groups=dataset.n_user_groups,
                                   user_to_user_group=dataset.user_to_user_group)
         return evaluate_recommender_algorithm(self.pointer_to_model, self.val_loader, evaluator, self.device,

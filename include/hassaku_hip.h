@@ -288,61 +288,80 @@ int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_col
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU fused step: one process per GPU; replaces nn.DataParallel (train/trainer.py:38-41).
  *
- * User tables are ROW-SHARDED: rank r owns the users u with u % world == r, stored at local row u / world
- * (base.user_emb and its moments hold only the local rows, base.n_users = number of local rows).  The item
- * table is replicated.  A step processes a global batch of world*batch positives; rank r takes positions
- * [r*batch, (r+1)*batch).  The library runs the compute phases; the caller runs the collectives between
- * them (RCCL through torch.distributed, or anything else that moves the buffers below):
+ * Both tables are SHARDED, nothing is replicated and no dense gradient is ever reduced:
+ *   items  range-sharded: rank r owns items [item_lo, item_lo + I_loc) with their AdamW moments
+ *          (base.item_emb / item_bias hold only those rows, base.n_items = I_loc);
+ *   users  row-sharded:   rank r owns the users u with u % world == r at local row u / world
+ *          (base.user_emb holds only those rows, base.n_users = number of local rows).
+ * A step processes a GLOBAL batch of G = world * batch positives.  Every rank draws the same Philox stream of
+ * negatives for the whole global batch and KEEPS THE ENTRIES WHOSE ITEM IT OWNS (exactly the single-GPU samples;
+ * no item row ever moves).  What moves are the batch's user rows and their gradients:
  *
- *   hsk_mp_prep        sample the local slice (RNG keyed by the GLOBAL batch position); route each positive's user
- *                      to its owner (slot_of_b; req_send[dst*C + s] = local row at dst, or -1).  The requests this
- *                      rank will RECEIVE need no exchange: every rank knows every slice of the global batch (same
- *                      COO, same epoch order), so req_recv is recomputed locally.  Owner: replay the missed
- *                      zero-gradient steps of the requested rows, pack them into rows_send
- *     all_to_all(rows_send -> rows_recv)                                  4*D*world*C bytes per rank
- *   hsk_mp_sort        item sort of the local entries -- independent of the exchange, so it overlaps it
- *   hsk_mp_forward     forward + loss + user-row grads (-> grads_send)              [needs rows_recv]
- *     all_to_all(grads_send -> grads_recv)                                4*D*world*C bytes per rank
- *   hsk_mp_item_grad   dense partial item gradient (-> g_item_emb, g_item_bias) -- overlaps that exchange
- *     all_reduce(g_item_emb, g_item_bias; sum)                            4*(D+1)*I bytes
- *   hsk_mp_apply_users owner: AdamW on the requested user rows (duplicates summed in slot order)  [needs grads_recv];
- *                      loss_out[0] = this rank's share of the global mean loss (sum over ranks = loss),
- *                      loss_out[1] accumulates it -- overlaps the all_reduce
- *   hsk_mp_apply_items AdamW on the (replicated) item table with the reduced gradient  [needs the all_reduce];
- *                      closes the step.  Must follow hsk_mp_apply_users.
+ *   hsk_shard_prepare      batch ids only (may run a step ahead on a side stream, buffer set `set`): sample + keep
+ *                          the owned entries (compact, per positive in column order), slot of every positive's user
+ *                          at its owner (slot_of_b = owner*C + position in batch order; every rank computes the whole
+ *                          map, so no request exchange), item sort of the kept entries, owner map of the requested rows
+ *   hsk_shard_pack         owner: replay the missed zero-gradient AdamW steps of the requested user rows, pack them
+ *     all_gather(rows_send [C,D] -> rows_all [world*C, D])                     4*D*C bytes to every peer
+ *   hsk_shard_pos_scores   s0[b] = <u_b, i_b0> + bias for the positives whose item this rank owns (0 elsewhere);
+ *                          lazily updated item rows of the batch are brought up to date first
+ *     all_reduce(s0 [G], sum)                                                   4*G bytes
+ *   hsk_shard_forward      per positive: scores of the OWNED negatives, d loss/d score, partial user-row gradient
+ *                          (-> dU_all[slot]), partial sum of the negatives' weights (-> gsum[b]), partial loss
+ *     all_reduce(gsum [G], sum)                                                 4*G bytes
+ *   hsk_shard_pos_fix      owner of the positive item: g_0 = -gsum[b]; dU_all[slot] += g_0 * i_b0
+ *     reduce_scatter(dU_all [world*C, D] -> grads_mine [C, D], sum)            4*D*C bytes to every peer
+ *   hsk_shard_apply_items  item-major gradient reduction + AdamW on the local item shard -- overlaps the reduce_scatter
+ *   hsk_shard_apply_users  owner: AdamW on the requested user rows (duplicates summed in slot order) [needs grads_mine];
+ *                          loss_out[0] = this rank's share of the global mean loss (sum over ranks = the loss),
+ *                          loss_out[1] accumulates it.  Closes the step.
  *
- * Result = the single-GPU step on the global batch (same samples; fp32 summation order of the item gradient
- * differs).  C = capacity (slots per rank pair); HSK_STATUS_ROUTE_OVERFLOW is raised if a pair needs more.
+ * Result = the single-GPU step on the global batch (same samples; the fp32 sums over a positive's negatives are split
+ * by owner, so the order of summation differs).  C = user slots per owner, entry_cap = kept entries per rank; if either
+ * is too small HSK_STATUS_SHARD_OVERFLOW is raised in *status (the step is then invalid).  BPR loss only.
+ * world == 1 is accepted (the collectives degenerate to copies): the same code path on one GPU.
  * ------------------------------------------------------------------------------------------ */
-enum { HSK_STATUS_ROUTE_OVERFLOW = 4 };
+enum { HSK_STATUS_SHARD_OVERFLOW = 4 };
 
-typedef struct hsk_bprmf_mp {
-  hsk_bprmf_state base;       /* local user shard + replicated item table; base.max_batch >= max(batch, world*C) */
+typedef struct hsk_bprmf_shard {
+  hsk_bprmf_state base;       /* LOCAL shards; base.max_batch >= max(world*batch, C), base.max_cols >= n_neg + 1;
+                                 base.csr_* / coo_* are the GLOBAL training interactions (global user / item ids) */
   int32_t world, rank;
-  int64_t n_users_global;
-  int64_t capacity;           /* C */
-  int32_t* req_send;          /* [world*C] */
-  int32_t* req_recv;          /* [world*C] */
-  float* rows_send;           /* [world*C, D] */
-  float* rows_recv;           /* [world*C, D] */
-  float* grads_send;          /* [world*C, D] */
-  float* grads_recv;          /* [world*C, D] */
-  float* g_item_emb;          /* [I, D] */
-  float* g_item_bias;         /* [I] (NULL without item bias) */
-  int32_t* slot_of_b;         /* [batch] */
-  int64_t cur_batch, cur_cols; /* library scratch: shape of the step in flight */
-  int64_t users_applied;       /* library scratch: hsk_mp_apply_users of the step in flight has run */
-} hsk_bprmf_mp;
+  int64_t n_users_global, n_items_global;
+  int64_t item_lo;            /* first global item id of the local shard (base.n_items rows) */
+  int64_t capacity;           /* C: user slots per owner rank */
+  int64_t entry_cap;          /* kept (positive, item) entries per rank and step, <= world*batch*(n_neg+1) */
+  void* shard_ws;             /* device scratch, hsk_shard_workspace_bytes() bytes, 256-byte aligned */
+  int64_t shard_ws_bytes;
+  float* rows_send;           /* [C, D]          all_gather input */
+  float* rows_all;            /* [world*C, D]    all_gather output */
+  float* dU_all;              /* [world*C, D]    reduce_scatter input (zero-initialised by the caller) */
+  float* grads_mine;          /* [C, D]          reduce_scatter output */
+  float* s0;                  /* [world*batch]   all_reduce in place */
+  float* gsum;                /* [world*batch]   all_reduce in place */
+  int64_t cur_batch, cur_cols; /* library scratch: shape of the step in flight (0: none) */
+  int32_t cur_set;             /* library scratch: buffer set of the step in flight */
+  int32_t phase;               /* library scratch: next expected phase */
+} hsk_bprmf_shard;
 
-int hsk_mp_prep(hsk_bprmf_mp* mp, const int64_t* order, int64_t start_global, int64_t batch, int64_t n_neg,
-                hsk_stream_t stream);
-int hsk_mp_sort(hsk_bprmf_mp* mp, hsk_stream_t stream);
-int hsk_mp_forward(hsk_bprmf_mp* mp, hsk_stream_t stream);
-int hsk_mp_item_grad(hsk_bprmf_mp* mp, hsk_stream_t stream);
-int hsk_mp_apply_users(hsk_bprmf_mp* mp, hsk_stream_t stream);
-int hsk_mp_apply_items(hsk_bprmf_mp* mp, hsk_stream_t stream);
-/* bring every local user row up to date (before evaluation / gathering the table) */
-int hsk_mp_flush(hsk_bprmf_mp* mp, hsk_stream_t stream);
+int64_t hsk_shard_workspace_bytes(int64_t max_batch, int64_t max_cols, int64_t capacity, int64_t entry_cap);
+int hsk_shard_init(hsk_bprmf_shard* sh, hsk_stream_t stream);   /* after hsk_bprmf_init_workspace(&sh->base) */
+int hsk_shard_prepare(hsk_bprmf_shard* sh, const int64_t* order, int64_t start_global, int64_t batch, int64_t n_neg,
+                      int32_t set, hsk_stream_t stream);
+/* a batch prepared in `set` that will not be trained on (a wrong guess of the next batch): releases its owner map */
+int hsk_shard_discard(hsk_bprmf_shard* sh, int32_t set, hsk_stream_t stream);
+int hsk_shard_pack(hsk_bprmf_shard* sh, int64_t batch, int64_t n_neg, int32_t set, hsk_stream_t stream);
+int hsk_shard_pos_scores(hsk_bprmf_shard* sh, hsk_stream_t stream);
+int hsk_shard_forward(hsk_bprmf_shard* sh, hsk_stream_t stream);
+int hsk_shard_pos_fix(hsk_bprmf_shard* sh, hsk_stream_t stream);
+int hsk_shard_apply_items(hsk_bprmf_shard* sh, hsk_stream_t stream);
+int hsk_shard_apply_users(hsk_bprmf_shard* sh, hsk_stream_t stream);
+/* bring every local user (and lazily updated item) row up to date (before evaluation / gathering the tables) */
+int hsk_shard_flush(hsk_bprmf_shard* sh, hsk_stream_t stream);
+/* debug / parity: the kept entries of the batch in flight or last prepared in `set`: counts per positive
+ * offs [world*batch + 1], local item ids items [entry_cap], user ids u [world*batch] (device int32 arrays) */
+int hsk_shard_last_batch(const hsk_bprmf_shard* sh, int32_t set, int64_t batch, int32_t* offs_out, int32_t* items_out,
+                         int32_t* u_out, hsk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Full-catalogue evaluation (eval/eval.py:237-253, eval/eval.py:54-99, eval/metrics.py:4-105)
@@ -353,6 +372,8 @@ int hsk_mp_flush(hsk_bprmf_mp* mp, hsk_stream_t stream);
  * (exact-fp32 MFMA); entries (u[r], item) present in the exclude CSR get -inf; then the k best per
  * row are returned sorted by (score desc, item id asc).  out_idx holds GLOBAL item ids.
  * scores_ws: [n_rows, item_count] floats of scratch (also the masked score matrix on return).
+ * Only rows [item_begin, item_begin + item_count) of item_emb / item_bias are dereferenced: a rank that holds just
+ * that range (item-sharded tables) passes shard - item_begin*dim (resp. shard_bias - item_begin) as the base.
  * Replaces get_item_representations(arange(I)) + combine_user_item_representations + mask +
  * logits.topk (eval/eval.py:240-251, :63) for one item shard.
  */

@@ -1,9 +1,13 @@
-"""Multi-process tests of the row-sharded multi-GPU step (hassaku_amd/dist.py).
+"""Multi-process tests of the item-sharded multi-GPU step and evaluation (hassaku_amd/dist.py, csrc/hsk_shard.inc).
 
-CPU (world_size 2, gloo): the PROTOCOL -- ownership, routing into fixed-capacity slots, the four collectives,
-owner-side accumulation -- executed with the oracle's arithmetic and compared with the un-sharded oracle step.
-GPU (2 ranks sharing cuda:0, gloo staging through the host): the real kernels through hsk_mp_*, compared with
-the single-GPU fused step on the same global batch, plus the users-sharded evaluation.
+CPU (world_size 2, gloo): the PROTOCOL -- item-range / user-row ownership, the kept-entries rule, slot routing, the four
+collectives (all_gather of user rows, all_reduce of the positive scores, all_reduce of the negatives' weights,
+reduce_scatter of the user-row gradients), owner-side accumulation -- executed with the oracle's arithmetic and
+compared with the un-sharded oracle step.
+GPU: the real kernels through hsk_shard_*: (a) ONE rank on backend nccl (= RCCL): every collective the step and the
+evaluation issue runs on RCCL with async_op / wait ordering against the kernels; (b) two ranks sharing cuda:0 (gloo
+staging through the host): the multi-rank semantics.  Both are compared with the single-GPU fused step on the same
+global batch, and the item-sharded evaluation with the single-GPU evaluation of the gathered tables.
 """
 import os
 import socket
@@ -29,93 +33,136 @@ def _free_port():
     return port
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend='gloo'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend == 'nccl':
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
 
 
 # ---------------------------------------------------------------------------------------------------
 # CPU: protocol with oracle arithmetic
 # ---------------------------------------------------------------------------------------------------
 def _route_host(gu, world, C):
-    """host restatement of k_route_requests: stable slot per destination, in batch order"""
-    req = -np.ones(world * C, dtype=np.int32)
+    """host restatement of k_shard_route: slot = owner*C + position among that owner's positives, in batch order"""
     slot_of_b = np.zeros(len(gu), dtype=np.int64)
+    req = -np.ones((world, C), dtype=np.int64)
     used = np.zeros(world, dtype=np.int64)
     for b, u in enumerate(gu):
         d = int(u % world)
         assert used[d] < C, 'capacity overflow'
-        req[d * C + used[d]] = u // world
+        req[d, used[d]] = u // world
         slot_of_b[b] = d * C + used[d]
         used[d] += 1
     return req, slot_of_b
 
 
+def _softplus(z):
+    return np.maximum(z, 0) + np.log1p(np.exp(-np.abs(z)))
+
+
 def _cpu_protocol_worker(rank, world, port, out_dir):
     _init(rank, world, port)
-    from hassaku_amd.dist import Comm, local_user_count, pair_capacity
+    from hassaku_amd.dist import Comm, item_range, local_user_count, user_capacity
     from oracle import oracle as orc
     comm = Comm()
     rng = np.random.RandomState(0)                      # same stream on every rank
     U, I, D, B, N, lr, wd = 37, 50, 16, 12, 5, 1e-2, 1e-3
+    G = world * B
     Ufull = (rng.randn(U, D) * 0.1).astype(np.float32)
-    Iw = (rng.randn(I, D) * 0.1).astype(np.float32)
-    Ib = (rng.randn(I) * 0.1).astype(np.float32)
-    C = pair_capacity(B, world)
-    Uloc = Ufull[rank::world].copy()
+    Ifull = (rng.randn(I, D) * 0.1).astype(np.float32)
+    Ibfull = (rng.randn(I) * 0.1).astype(np.float32)
+    C = user_capacity(0.6, G)
+    lo, hi = item_range(I, rank, world)
+    Uloc, Iloc, Ibloc = Ufull[rank::world].copy(), Ifull[lo:hi].copy(), Ibfull[lo:hi].copy()
     assert Uloc.shape[0] == local_user_count(U, rank, world)
     mU, vU = np.zeros_like(Uloc), np.zeros_like(Uloc)
-    mI, vI, mIb, vIb = np.zeros_like(Iw), np.zeros_like(Iw), np.zeros_like(Ib), np.zeros_like(Ib)
-    ref = orc.MfOracleTrainer(Ufull, Iw, Ib, lr=lr, wd=wd) if rank == 0 else None
+    mI, vI, mIb, vIb = np.zeros_like(Iloc), np.zeros_like(Iloc), np.zeros_like(Ibloc), np.zeros_like(Ibloc)
+    ref = orc.MfOracleTrainer(Ufull, Ifull, Ibfull, lr=lr, wd=wd) if rank == 0 else None
+    losses = []
     for step in range(1, 5):
-        gu = rng.randint(0, U, size=world * B).astype(np.int64)            # the GLOBAL batch, known to all
-        gu[1] = gu[0]                                                       # duplicate users, also across ranks
+        gu = rng.randint(0, U, size=G).astype(np.int64)                    # the GLOBAL batch, known to all
+        gu[1] = gu[0]                                                       # duplicate users, also across slices
         gu[B] = gu[0]
-        gi = rng.randint(0, I, size=(world * B, N + 1)).astype(np.int64)
-        lu, li = gu[rank * B:(rank + 1) * B], gi[rank * B:(rank + 1) * B]
-        req, slot_of_b = _route_host(lu, world, C)
-        # the owner recomputes the requests it will receive from the global batch every rank knows ...
-        req_recv = np.concatenate([_route_host(gu[s * B:(s + 1) * B], world, C)[0][rank * C:(rank + 1) * C]
-                                   for s in range(world)])
-        # ... which is exactly what exchanging them would deliver
-        exchanged = torch.empty(world * C, dtype=torch.int32)
-        comm.all_to_all(exchanged, torch.from_numpy(req))
-        assert np.array_equal(exchanged.numpy(), req_recv)
-        rows_send = np.zeros((world * C, D), np.float32)
-        ok = req_recv >= 0
-        rows_send[ok] = Uloc[req_recv[ok]]
-        rows_recv = torch.empty((world * C, D))
-        comm.all_to_all(rows_recv, torch.from_numpy(rows_send))
-        Ub = rows_recv.numpy()[slot_of_b]                                   # [B, D] rows of my batch users
-        # local compute with the oracle's closed forms; the loss mean is over the GLOBAL batch
-        logits = orc.mf_scores(Ub, Iw, Ib, None, None, np.arange(B), li)
-        _, g_local = orc.bpr_loss_grad(logits)
-        g = g_local / world
-        gU, gI, gIb, _, _ = orc.mf_backward(Ub, Iw, np.arange(B), li, g)
-        red = torch.from_numpy(np.concatenate([gI.reshape(-1), gIb]))
-        comm.all_reduce(red)
-        gI, gIb = red.numpy()[:I * D].reshape(I, D), red.numpy()[I * D:]
-        grads_send = np.zeros((world * C, D), np.float32)
-        grads_send[slot_of_b] = gU                                          # gU is per batch position (identity index)
-        grads_recv = torch.empty((world * C, D))
-        comm.all_to_all(grads_recv, torch.from_numpy(grads_send))
-        # owner: sum the slots of each row in slot order, dense AdamW on the local shard
+        gi = rng.randint(0, I, size=(G, N + 1)).astype(np.int64)
+        req, slot_of_b = _route_host(gu, world, C)
+        # owner -> everyone: the batch's user rows
+        send = np.zeros((C, D), np.float32)
+        ok = req[rank] >= 0
+        send[ok] = Uloc[req[rank][ok]]
+        rows_all = torch.empty((world * C, D))
+        comm.all_gather_into(rows_all, torch.from_numpy(send))
+        Ub = rows_all.numpy()[slot_of_b]                                    # [G, D]
+        mine = (gi >= lo) & (gi < hi)                                       # the entries this rank keeps
+        # positive scores by the positive item's owner
+        s0 = np.zeros(G, np.float32)
+        own_pos = mine[:, 0]
+        s0[own_pos] = (Ub[own_pos] * Iloc[gi[own_pos, 0] - lo]).sum(-1) + Ibloc[gi[own_pos, 0] - lo]
+        s0_t = torch.from_numpy(s0)
+        comm.all_reduce(s0_t)
+        s0 = s0_t.numpy()
+        # owned negatives: weights, partial user-row gradients, partial weight sums, partial loss
+        inv = np.float32(1.0 / (G * N))
+        dU = np.zeros((world * C, D), np.float32)
+        gsum = np.zeros(G, np.float32)
+        gI, gIb = np.zeros_like(Iloc), np.zeros_like(Ibloc)
+        loss_part = 0.0
+        g_entry = np.zeros((G, N + 1), np.float32)
+        for b in range(G):
+            for k in range(1, N + 1):
+                if not mine[b, k]:
+                    continue
+                j = gi[b, k] - lo
+                x = s0[b] - (np.dot(Ub[b], Iloc[j]) + Ibloc[j])
+                g = inv / (1.0 + np.exp(x))
+                g_entry[b, k] = g
+                gsum[b] += g
+                dU[slot_of_b[b]] += g * Iloc[j]
+                loss_part += _softplus(-x)
+        gs_t = torch.from_numpy(gsum)
+        comm.all_reduce(gs_t)
+        gsum = gs_t.numpy()
+        for b in np.nonzero(own_pos)[0]:
+            g_entry[b, 0] = -gsum[b]
+            dU[slot_of_b[b]] += -gsum[b] * Iloc[gi[b, 0] - lo]
+        grads_mine = torch.empty((C, D))
+        comm.reduce_scatter(grads_mine, torch.from_numpy(dU))
+        # local item gradient (never leaves the rank) + AdamW on the shard
+        for b in range(G):
+            for k in range(N + 1):
+                if mine[b, k]:
+                    gI[gi[b, k] - lo] += g_entry[b, k] * Ub[b]
+                    gIb[gi[b, k] - lo] += g_entry[b, k]
+        orc.adamw_step(Iloc, gI, mI, vI, lr, wd, step)
+        orc.adamw_step(Ibloc, gIb, mIb, vIb, lr, wd, step)
+        # owner: sum the slots of each row in slot order, dense AdamW on the local user shard
         gloc = np.zeros_like(Uloc)
-        for s in range(world * C):
-            if req_recv[s] >= 0:
-                gloc[req_recv[s]] += grads_recv.numpy()[s]
+        for s in range(C):
+            if req[rank][s] >= 0:
+                gloc[req[rank][s]] += grads_mine.numpy()[s]
         orc.adamw_step(Uloc, gloc, mU, vU, lr, wd, step)
-        orc.adamw_step(Iw, np.ascontiguousarray(gI), mI, vI, lr, wd, step)
-        orc.adamw_step(Ib, np.ascontiguousarray(gIb), mIb, vIb, lr, wd, step)
+        lt = torch.tensor([loss_part / (G * N)], dtype=torch.float64)
+        comm.all_reduce(lt)
+        losses.append(float(lt.item()))
         if ref is not None:
-            ref.step(gu, gi)
-    parts = comm.all_gather(torch.from_numpy(np.pad(Uloc, ((0, local_user_count(U, 0, world) - Uloc.shape[0]), (0, 0)))))
+            assert abs(ref.step(gu, gi)[0] - losses[-1]) < 1e-6 * abs(losses[-1])
+    pad = lambda a, n: np.pad(a, ((0, n - a.shape[0]),) + ((0, 0),) * (a.ndim - 1))
+    parts = comm.all_gather(torch.from_numpy(pad(Uloc, local_user_count(U, 0, world))))
+    n_max = max(item_range(I, r, world)[1] - item_range(I, r, world)[0] for r in range(world))
+    iparts = comm.all_gather(torch.from_numpy(pad(Iloc, n_max)))
+    bparts = comm.all_gather(torch.from_numpy(pad(Ibloc, n_max)))
     if rank == 0:
         full = np.empty_like(Ufull)
         for r, p in enumerate(parts):
             full[r::world] = p.numpy()[:local_user_count(U, r, world)]
-        np.savez(os.path.join(out_dir, 'res.npz'), U=full, I=Iw, Ib=Ib, rU=ref.P['user_emb'], rI=ref.P['item_emb'],
+        sizes = [item_range(I, r, world)[1] - item_range(I, r, world)[0] for r in range(world)]
+        fi = np.concatenate([p.numpy()[:n] for p, n in zip(iparts, sizes)])
+        fb = np.concatenate([p.numpy()[:n] for p, n in zip(bparts, sizes)])
+        np.savez(os.path.join(out_dir, 'res.npz'), U=full, I=fi, Ib=fb, rU=ref.P['user_emb'], rI=ref.P['item_emb'],
                  rIb=ref.P['item_bias'])
     dist.destroy_process_group()
 
@@ -131,15 +178,29 @@ def test_sharded_protocol_equals_unsharded_oracle(tmp_path):
     assert_adam_param_close(r['Ib'], r['rIb'], 'item_bias')
 
 
-def test_ownership_capacity_and_csr_shards():
+def test_ownership_capacities_and_csr_shards():
     from hassaku_amd.data.csr import UserItemCsr
-    from hassaku_amd.dist import local_user_count, owner_of, pair_capacity
+    from hassaku_amd.dist import entry_capacity, item_range, local_user_count, owner_of, user_capacity
     assert [local_user_count(10, r, 4) for r in range(4)] == [3, 3, 2, 2]
     o, l = owner_of(np.arange(10), 4)
     assert list(o) == [0, 1, 2, 3, 0, 1, 2, 3, 0, 1] and list(l) == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
-    for B, W in ((4096, 8), (4096, 2), (128, 4), (8, 8)):
-        C = pair_capacity(B, W)
-        assert B / W < C <= B and C % 4 == 0 or C == B
+    for I, W in ((10677, 8), (131072, 8), (7, 3), (10_000_000, 8)):
+        ranges = [item_range(I, r, W) for r in range(W)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == I
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert max(h - l for l, h in ranges) - min(h - l for l, h in ranges) <= 1
+    for G, W in ((32768, 8), (8192, 2), (512, 4), (8, 8), (128, 1)):
+        C = user_capacity(1.0 / W, G)
+        assert G / W <= C <= G and (C % 4 == 0 or C == G)
+        cap = entry_capacity(1.0 / W, G, 100)
+        assert G * 100 / W < cap <= G * 101
+    assert user_capacity(1.0, 128) == 128 and entry_capacity(1.0, 128, 10) == 128 * 11
+    # the cfg5 shard fits the item sort on its own: 10 M items over 8 ranks = 1.25 M per shard (cap 4.19 M per device)
+    from hassaku_amd import _lib
+    if os.path.isfile(_lib.LIB_PATH):
+        lib = _lib.load()
+        assert lib.hsk_bprmf_workspace_bytes(1000, 10_000_000 // 8, 1024, 8 * 1024, 201) > 0
+        assert lib.hsk_bprmf_workspace_bytes(1000, 10_000_000, 1024, 8 * 1024, 201) < 0
     rng = np.random.RandomState(0)
     pairs = np.argwhere(rng.rand(11, 30) < 0.3)
     csr = UserItemCsr.from_pairs(pairs[:, 0], pairs[:, 1], 11, 30)
@@ -151,11 +212,10 @@ def test_ownership_capacity_and_csr_shards():
 
 
 # ---------------------------------------------------------------------------------------------------
-# GPU: the real kernels, two ranks on one device
+# GPU: the real kernels
 # ---------------------------------------------------------------------------------------------------
-def _toy_problem():
+def _toy_problem(D=64, N=12, U=211, I=300, B=48):
     rng = np.random.RandomState(3)
-    U, I, D, B, N = 211, 300, 64, 48, 12
     pairs = np.argwhere(rng.rand(U, I) < 0.06)
     pairs = pairs[rng.permutation(len(pairs))]
     P = {'user_emb': (rng.randn(U, D) * 0.05).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.05).astype(np.float32),
@@ -164,99 +224,196 @@ def _toy_problem():
     return U, I, D, B, N, pairs, P, val
 
 
-def _gpu_worker(rank, world, port, out_dir):
-    _init(rank, world, port)
+def _dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dt) if dt else t).cuda()
+
+
+class _EvalDs:   # the attributes the evaluators read from a FullEvalDataset
+    def __init__(self, pairs, val, U, I):
+        from hassaku_amd.data.csr import UserItemCsr
+        self.label_csr = UserItemCsr.from_pairs(val[:, 0], val[:, 1], U, I)
+        self.exclude_csr = UserItemCsr.from_pairs(pairs[:, 0], pairs[:, 1], U, I)
+        self.n_users, self.n_items = U, I
+        self._device_cache = {}
+
+    def device_arrays(self, device):
+        lp, li = self.label_csr.to_device(device)
+        ep, ei = self.exclude_csr.to_device(device)
+        return {'label_indptr': lp, 'label_indices': li, 'excl_indptr': ep, 'excl_indices': ei}
+
+
+def _shard_worker(rank, world, port, out_dir, backend, shape, n_steps, lazy_items, prefetch):
+    _init(rank, world, port, backend)
     torch.cuda.set_device(0)
     from conftest import csr_from_pairs
-    from hassaku_amd.data.csr import UserItemCsr
-    from hassaku_amd.dist import Comm, ShardedBprMf, evaluate_sharded
+    from hassaku_amd.dist import Comm, ShardedBprMf, evaluate_item_sharded
     from hassaku_amd.eval.eval import FullEvaluator
     comm = Comm()
-    U, I, D, B, N, pairs, P, val = _toy_problem()
+    assert comm.native == (backend == 'nccl')
+    U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
     ptr, idx = csr_from_pairs(pairs, U)
-    dev = lambda a, dt=None: (torch.from_numpy(np.ascontiguousarray(a)).to(dt) if dt else torch.from_numpy(np.ascontiguousarray(a))).cuda()
-    t = {k: dev(v) for k, v in P.items()}
+    t = {k: _dev(v) for k, v in P.items()}
     sh = ShardedBprMf(comm, t['user_emb'], t['item_emb'], t['item_bias'], t['user_bias'], None, lr=2e-3, wd=1e-4,
-                      batch=B, n_neg=N, csr_indptr=dev(ptr), csr_indices=dev(idx), coo_user=dev(pairs[:, 0], torch.int32),
-                      coo_item=dev(pairs[:, 1], torch.int32), seed=77)
+                      batch=B, n_neg=N, csr_indptr=_dev(ptr), csr_indices=_dev(idx), coo_user=_dev(pairs[:, 0], torch.int32),
+                      coo_item=_dev(pairs[:, 1], torch.int32), seed=77, lazy_items=lazy_items, prefetch=prefetch)
     order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
+    G = world * B
+    n_slices = len(pairs) // G
     losses = []
-    n_steps = 70                                   # crosses the periodic flush at step 64
     for s in range(n_steps):
-        sh.step_sampled(order, (s % 4) * world * B)
+        nxt = ((s + 1) % n_slices) * G if s + 1 < n_steps else None
+        if s == 5:
+            nxt = 0                                 # a wrong guess: the prepared batch must be discarded
+        sh.step_sampled(order, (s % n_slices) * G, next_start=nxt)
         if s % 9 == 0:
             losses.append(sh.last_loss())
     sh.check_status()
+    # kept entries of the last batch: every rank keeps exactly the global sample's entries inside its item range
+    offs, items, ug = (x.cpu().numpy() for x in sh.last_batch())
     full_u, full_ub = sh.gather_user_table()
-
-    class DS:   # the attributes the evaluators read from a FullEvalDataset
-        def device_arrays(self, device):
-            lp, li = self.label_csr.to_device(device)
-            ep, ei = self.exclude_csr.to_device(device)
-            return {'label_indptr': lp, 'label_indices': li, 'excl_indptr': ep, 'excl_indices': ei}
-    ds = DS()
-    ds.label_csr = UserItemCsr.from_pairs(val[:, 0], val[:, 1], U, I)
-    ds.exclude_csr = UserItemCsr.from_pairs(pairs[:, 0], pairs[:, 1], U, I)
-    ds._device_cache = {}
+    full_i, full_ib = sh.gather_item_table()
+    ds = _EvalDs(pairs, val, U, I)
     groups = torch.from_numpy((np.arange(U) % 2).astype(np.float32))
     ev = FullEvaluator(aggr_by_group=True, n_groups=2, user_to_user_group=groups)
-    metrics = evaluate_sharded(comm, sh, ds, ev, chunk=64)
-    from hassaku_amd.dist import evaluate_item_sharded
-    m_items = evaluate_item_sharded(comm, full_u, sh.item_emb, sh.item_bias, full_ub, None, ds, ev, chunk=50)
-    assert sorted(m_items) == sorted(metrics)
-    for k in metrics:   # item-sharded scoring + candidate all-gather + merge == users-sharded scoring
-        assert abs(m_items[k] - metrics[k]) < 1e-9, (k, m_items[k], metrics[k])
+    metrics = evaluate_item_sharded(comm, sh, ds, ev, chunk=64)
+    np.savez(os.path.join(out_dir, f'kept{rank}.npz'), offs=offs, items=items, ug=ug, lo=sh.item_lo, hi=sh.item_hi)
     if rank == 0:
         np.savez(os.path.join(out_dir, 'mp.npz'), U=full_u.cpu().numpy(), Ub=full_ub.cpu().numpy(),
-                 I=sh.item_emb.cpu().numpy(), Ib=sh.item_bias.cpu().numpy(), losses=np.array(losses),
+                 I=full_i.cpu().numpy(), Ib=full_ib.cpu().numpy(), losses=np.array(losses),
                  metric_names=np.array(sorted(metrics)), metric_values=np.array([metrics[k] for k in sorted(metrics)]))
     dist.destroy_process_group()
 
 
-@pytest.mark.gpu
-def test_two_rank_sharded_step_equals_single_gpu_step(tmp_path):
-    from conftest import assert_adam_param_close, csr_from_pairs
+def _single_gpu_reference(world, shape, n_steps, lazy_items='auto'):
+    """The same global batches through the single-GPU fused step: same seed / order / step numbering -> same samples."""
+    from conftest import csr_from_pairs
     from hassaku_amd import hip_ops as ops
-    from hassaku_amd.data.csr import UserItemCsr
-    world = 2
-    mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    r = np.load(os.path.join(str(tmp_path), 'mp.npz'))
-    # single GPU, global batch world*B, same seed / order / step numbering -> same samples
-    U, I, D, B, N, pairs, P, val = _toy_problem()
+    U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
     ptr, idx = csr_from_pairs(pairs, U)
-    dev = lambda a, dt=None: (torch.from_numpy(np.ascontiguousarray(a)).to(dt) if dt else torch.from_numpy(np.ascontiguousarray(a))).cuda()
-    t = {k: dev(v) for k, v in P.items()}
+    t = {k: _dev(v) for k, v in P.items()}
+    G = world * B
     st = ops.BprMfFusedState(t['user_emb'], t['item_emb'], t['item_bias'], t['user_bias'], None, lr=2e-3, wd=1e-4,
-                             max_batch=world * B, max_cols=N + 1, seed=77, csr_indptr=dev(ptr), csr_indices=dev(idx),
-                             coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+                             max_batch=G, max_cols=N + 1, seed=77, csr_indptr=_dev(ptr), csr_indices=_dev(idx),
+                             coo_user=_dev(pairs[:, 0], torch.int32), coo_item=_dev(pairs[:, 1], torch.int32),
+                             lazy_items=lazy_items)
     order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
+    n_slices = len(pairs) // G
     losses = []
-    for s in range(70):
-        st.step_sampled(order, (s % 4) * world * B, world * B, N)
+    for s in range(n_steps):
+        st.step_sampled(order, (s % n_slices) * G, G, N)
         if s % 9 == 0:
             losses.append(st.last_loss())
     st.flush()
     st.check_status()
-    np.testing.assert_allclose(r['losses'], np.array(losses), rtol=2e-5)
+    lu, li = st.last_batch(G, N + 1)
+    return t, np.array(losses), lu.cpu().numpy(), li.cpu().numpy()
+
+
+def _check_against_single_gpu(tmp_path, world, shape, n_steps):
+    from conftest import assert_adam_param_close
+    from hassaku_amd import hip_ops as ops
+    from hassaku_amd.data.csr import UserItemCsr
+    r = np.load(os.path.join(str(tmp_path), 'mp.npz'))
+    t, losses, lu, li = _single_gpu_reference(world, shape, n_steps)
+    U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
+    # the samples: each rank kept exactly the entries of the single-GPU batch that fall into its item range,
+    # positive first, negatives in column order
+    for rank in range(world):
+        k = np.load(os.path.join(str(tmp_path), f'kept{rank}.npz'))
+        lo, hi = int(k['lo']), int(k['hi'])
+        assert np.array_equal(k['ug'], lu)
+        for b in range(world * B):
+            want = [x - lo for x in li[b] if lo <= x < hi]
+            assert list(k['items'][k['offs'][b]:k['offs'][b + 1]]) == want, (rank, b)
+    np.testing.assert_allclose(r['losses'], losses, rtol=2e-5)
     assert_adam_param_close(r['U'], t['user_emb'].cpu().numpy(), 'user_emb')
     assert_adam_param_close(r['Ub'], t['user_bias'].cpu().numpy(), 'user_bias')
     assert_adam_param_close(r['I'], t['item_emb'].cpu().numpy(), 'item_emb')
     assert_adam_param_close(r['Ib'], t['item_bias'].cpu().numpy(), 'item_bias')
-    # users-sharded evaluation == single-GPU evaluation of the gathered tables
+    # item-sharded evaluation == single-GPU evaluation of the gathered tables
     lab = UserItemCsr.from_pairs(val[:, 0], val[:, 1], U, I)
     exc = UserItemCsr.from_pairs(pairs[:, 0], pairs[:, 1], U, I)
-    lp, li = lab.to_device('cuda')
+    lp, lix = lab.to_device('cuda')
     ep, ei = exc.to_device('cuda')
     ks = [100, 50, 10, 5]
     u = torch.arange(U, device='cuda')
-    _, ids, _ = ops.mf_eval_topk(dev(r['U']), dev(r['I']), dev(r['Ib']), dev(r['Ub']), None, u, 100, ep, ei)
-    met = ops.rank_metrics(ids, u, lp, li, ks).double().cpu().numpy()
+    _, ids, _ = ops.mf_eval_topk(_dev(r['U']), _dev(r['I']), _dev(r['Ib']), _dev(r['Ub']), None, u, 100, ep, ei)
+    met = ops.rank_metrics(ids, u, lp, lix, ks).double().cpu().numpy()
     got = dict(zip([str(x) for x in r['metric_names']], r['metric_values']))
     grp = np.arange(U) % 2
     for tt, k in enumerate(ks):
         for j, name in enumerate(('precision', 'recall', 'ndcg')):
             assert abs(got[f'{name}@{k}'] - met[:, tt, j].mean()) < 1e-9, (name, k)
             assert abs(got[f'group_1_{name}@{k}'] - met[grp == 1, tt, j].mean()) < 1e-9, (name, k)
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_sharded_step_equals_single_gpu_step(tmp_path):
+    """backend nccl with ONE rank: all_gather_into / all_reduce / reduce_scatter / all_to_all of the step and the
+    evaluation run on RCCL itself (async_op + wait against kernels on the current stream, the side-stream prefetch),
+    70 steps across the periodic flush; results = the single-GPU step."""
+    shape = dict(D=64, N=12)
+    mp.spawn(_shard_worker, args=(1, _free_port(), str(tmp_path), 'nccl', shape, 70, 'auto', True), nprocs=1, join=True)
+    _check_against_single_gpu(tmp_path, 1, shape, 70)
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_step_equals_single_gpu_step(tmp_path):
+    shape = dict(D=64, N=12)
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path), 'gloo', shape, 70, 'auto', True), nprocs=2, join=True)
+    _check_against_single_gpu(tmp_path, 2, shape, 70)
+
+
+@pytest.mark.gpu
+def test_three_rank_lazy_items_no_prefetch(tmp_path):
+    """odd world size (uneven item ranges, uneven user shards), lazy item AdamW on the shards, D = 402 (float2 rows)"""
+    shape = dict(D=402, N=7, U=97, I=1000, B=20)
+    mp.spawn(_shard_worker, args=(3, _free_port(), str(tmp_path), 'gloo', shape, 66, True, False), nprocs=3, join=True)
+    _check_against_single_gpu(tmp_path, 3, shape, 66)
+
+
+@pytest.mark.gpu
+def test_cfg5_shaped_sharded_smoke(tmp_path):
+    """BASELINE configs[4] row shape (D=1024, neg_train=200) with both tables sharded over two ranks; tables scaled
+    to fit, catalogue large against the batch so the item shards run the lazy AdamW path as cfg5 would"""
+    shape = dict(D=1024, N=200, U=400, I=30000, B=16)
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path), 'gloo', shape, 6, 'auto', True), nprocs=2, join=True)
+    _check_against_single_gpu(tmp_path, 2, shape, 6)
+
+
+def _comm_worker(rank, world, port, out_dir):
+    _init(rank, world, port, 'nccl')
+    from hassaku_amd.dist import Comm
+    comm = Comm()
+    assert comm.native
+    dev = torch.device('cuda', 0)
+    a = torch.arange(12, dtype=torch.float32, device=dev).view(4, 3)
+    out = torch.empty_like(a)
+    w = comm.all_gather_into(out, a, async_op=True)
+    busy = torch.ones(1 << 20, device=dev).cumsum(0)             # independent work queued under the collective
+    w.wait()
+    assert torch.equal(out, a)
+    w = comm.reduce_scatter(out, a * 2, async_op=True)
+    w.wait()
+    assert torch.equal(out, a * 2)
+    w = comm.all_to_all(out, a + 1, async_op=True)
+    w.wait()
+    assert torch.equal(out, a + 1)
+    t = a.clone()
+    comm.all_reduce(t)
+    comm.all_reduce(t, op='max')
+    assert torch.equal(t, a)
+    assert torch.equal(comm.all_gather(a)[0], a)
+    comm.broadcast(t, src=0)
+    comm.barrier()
+    assert float(busy[-1].item()) == float(1 << 20)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_comm_native_branches_on_rccl(tmp_path):
+    mp.spawn(_comm_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
 
 
 def _trainer_worker(rank, world, port, out_dir):
@@ -279,7 +436,7 @@ def _trainer_worker(rank, world, port, out_dir):
 @pytest.mark.gpu
 def test_two_rank_run_train_val(tmp_path):
     """`torchrun --nproc-per-node 2 run_experiment.py` equivalent: both ranks agree on the metrics, rank 0 wrote a
-    complete model.pth (user table gathered from the shards) that evaluates to the same validation metrics."""
+    complete model.pth (user and item tables gathered from the shards) that evaluates to the same validation metrics."""
     import json
     from hassaku_amd.data.synthetic import generate, write_csv_dataset
     ds_path = str(tmp_path / 'data' / 'ml100k' / 'processed_dataset')

@@ -53,9 +53,9 @@ def _header_fields(struct_name):
 
 def test_state_struct_layout_matches_header():
     """Field order of the ctypes mirrors == field order of the structs in the header."""
-    from hassaku_amd._lib import HskBprmfMp, HskBprmfState
+    from hassaku_amd._lib import HskBprmfShard, HskBprmfState
     assert _header_fields('hsk_bprmf_state') == [f[0] for f in HskBprmfState._fields_]
-    assert _header_fields('hsk_bprmf_mp') == [f[0] for f in HskBprmfMp._fields_]
+    assert _header_fields('hsk_bprmf_shard') == [f[0] for f in HskBprmfShard._fields_]
 
 
 def test_workspace_size_is_pure_host_arithmetic():
