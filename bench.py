@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BPR triplets/s of the fused MI355X BPR-MF training step (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ml10m|ml1m|ml100k]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ml10m|ml1m|ml100k|lfm2b|hbm]
 
 One "step" = one full training step of Trainer.fit on one batch of synthetic interactions: on-device
 uniform rejection sampling of the negatives, embedding gathers, (u.i - u.j) scores with item bias,
@@ -10,19 +10,31 @@ torch.optim.AdamW).  Inputs (tables, interaction CSR/COO, the epoch permutation)
 before the timed region.  Default workload: BASELINE.json configs[2] (ml10m shape, D=512, N=100,
 B=4096) -- the configuration the metric "% HBM-read roofline at dim=512" is quoted on.
 
-Rank 0 prints ONE JSON line (see the driver contract).  `roofline` describes the gather+BPR kernel
-(k_fwd_ugrad): algorithmic read bytes per launch / its mean duration, measured with HIP events on
-the launch stream inside the timed region.  `cpu_baseline` times the CPU restatement of the
-reference's trainer (oracle/cpu_trainer.py, kind "port") on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line (see the driver contract).  Besides the contract's keys it carries, all timed inside
+this run:
+  roofline      the gather+BPR kernel (k_fwd_ugrad) of the headline workload: algorithmic read bytes per launch / its
+                mean duration (HIP events of the kernel's own dispatch on the launch stream, inside the timed region).
+                At the ml10m shape the tables live in L2 + Infinity Cache, so the bound is the cache fabric, not HBM
+  workloads     (N=1) the other BASELINE training configs -- ml1m (configs[1]), ml100k (configs[0]) -- and `hbm`,
+                the same step on tables no cache can hold, whose roofline IS the HBM-read roofline of the kernel
+  eval          full-catalogue evaluation users/s (ml10m and lfm2b shapes at N=1; item-sharded lfm2b at N>1)
+  cpu_baseline  (N=1) the CPU restatement of the reference's trainer (oracle/cpu_trainer.py, kind "port"): a bounded
+                sample of the headline workload + the SURVEY 8(d) protocol on configs[0] (20 + 200 steps, 0 and 4
+                loader workers)
+N > 1 (one process per GPU, RCCL): item table range-sharded, user table row-sharded, global batch N*B (weak scaling).
 """
-import argparse
-import json
 import os
-import sys
-import time
 
-import numpy as np
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for RCCL; must be set before HIP initialises
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+
+import argparse  # noqa: E402
+import json      # noqa: E402
+import sys       # noqa: E402
+import time      # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch        # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -37,9 +49,13 @@ WORKLOADS = {
     # not a BASELINE config: the ml10m step on tables that cannot be cached (the honest HBM point for k_fwd_ugrad)
     'hbm': ('hbm', 512, 100, 4096),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = 'r1e_final'  # committed rocprofv3 summaries of `bench.py` (profiles/README.md)
-LR, WD = 3e-4, 4e-5    # README.md:82-83 of the reference (canonical BPR-MF conf)
+EVAL_SHAPES = {'ml10m': (69878, 10677, 512, 82), 'lfm2b': (16384, 131072, 512, 120)}   # U, I, D, positives per user
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+ICACHE_GATHER_GBS = 8600.0   # same guide, "Indexed rows": uniformly random rows of an Infinity-Cache-resident table
+HBM_GATHER_GBS = 5750.0      # same guide: random 2.3 KB rows of a table far beyond the Infinity Cache, 5.7-5.8 TB/s
+MFMA_FP32_TFLOPS = 157.0     # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32; no xf32 on gfx950)
+PROFILE_DIR = {'ml10m': 'r2_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2_ml1m'}  # committed rocprofv3 summaries per workload
+LR, WD = 3e-4, 4e-5          # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
 def fwd_read_bytes(B, N, D):
@@ -48,61 +64,254 @@ def fwd_read_bytes(B, N, D):
     return 4 * D * B * (2 + N) + 4 * B * (1 + N) + 4 * B * (1 + N) + 4 * B
 
 
-def pmc_traffic_bytes(kernel_prefix, profile_dir):
-    """HBM-side traffic of one launch from the committed rocprofv3 PMC passes of this same command
-    (`tools_profile.sh`; FETCH_SIZE and WRITE_SIZE are collected in separate runs and reported in KB).  On gfx950
-    FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM): x2."""
-    path = os.path.join(REPO, 'profiles', profile_dir, 'pmc_summary.json')
-    if not os.path.isfile(path):
-        return None
+def pmc_traffic(kernel_prefix, workload):
+    """HBM-side traffic of one launch from the COMMITTED rocprofv3 PMC passes of this same command (tools_profile.sh;
+    FETCH_SIZE and WRITE_SIZE are collected in separate runs and reported in KB).  On gfx950 FETCH_SIZE counts 64 B
+    per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM): x2.  -> (bytes | None, source)."""
+    d = PROFILE_DIR.get(workload)
+    path = os.path.join(REPO, 'profiles', d or '', 'pmc_summary.json')
+    if not d or not os.path.isfile(path):
+        return None, None
     for name, row in json.load(open(path)).items():
         if name.startswith(kernel_prefix) and 'FETCH_SIZE_KB_mean' in row and 'WRITE_SIZE_KB_mean' in row:
-            return (2.0 * row['FETCH_SIZE_KB_mean'] + row['WRITE_SIZE_KB_mean']) * 1024.0
-    return None
+            return ((2.0 * row['FETCH_SIZE_KB_mean'] + row['WRITE_SIZE_KB_mean']) * 1024.0,
+                    f'committed profile profiles/{d}/pmc_summary.json (rocprofv3 --pmc of this command; not re-measured by this run)')
+    return None, None
 
 
-def build_state(data, D, B, N, device, seed=64, **kw):
-    from hassaku_amd import hip_ops as ops
-    from hassaku_amd.data.csr import UserItemCsr
-    U, I = data.n_users, data.n_items
-    csr = UserItemCsr.from_pairs(data.train[:, 0], data.train[:, 1], U, I)
+def init_tables(U, I, D, device, seed=64):
     torch.manual_seed(seed)
     user_emb = torch.empty((U, D), device=device).normal_(std=0.1 / D)   # train/utils.py:12-13 of the reference
     item_emb = torch.empty((I, D), device=device).normal_(std=0.1 / D)
     item_bias = torch.empty((I,), device=device).normal_(std=0.1)        # [I,1] table: std 0.1/1
+    return user_emb, item_emb, item_bias
+
+
+def device_interactions(data, device):
+    from hassaku_amd.data.csr import UserItemCsr
+    csr = UserItemCsr.from_pairs(data.train[:, 0], data.train[:, 1], data.n_users, data.n_items)
     indptr, indices = csr.to_device(device)
     coo_u = torch.from_numpy(data.train[:, 0].astype(np.int32)).to(device)
     coo_i = torch.from_numpy(data.train[:, 1].astype(np.int32)).to(device)
+    return csr, dict(csr_indptr=indptr, csr_indices=indices, coo_user=coo_u, coo_item=coo_i)
+
+
+def build_state(data, D, B, N, device, seed=64, **kw):
+    from hassaku_amd import hip_ops as ops
+    csr, arrays = device_interactions(data, device)
+    user_emb, item_emb, item_bias = init_tables(data.n_users, data.n_items, D, device, seed)
     st = ops.BprMfFusedState(user_emb, item_emb, item_bias, lr=LR, wd=WD, max_batch=B, max_cols=N + 1, seed=seed,
-                             csr_indptr=indptr, csr_indices=indices, coo_user=coo_u, coo_item=coo_i, **kw)
+                             **arrays, **kw)
     return st, csr
 
 
-def build_sharded_state(data, D, B, N, device, seed=64):
-    """world > 1: row-sharded user tables + replicated item table (hassaku_amd/dist.py); B positives per rank."""
-    from hassaku_amd.data.csr import UserItemCsr
-    from hassaku_amd.dist import Comm, ShardedBprMf
-    comm = Comm()
-    U, I = data.n_users, data.n_items
-    csr = UserItemCsr.from_pairs(data.train[:, 0], data.train[:, 1], U, I)
-    torch.manual_seed(seed)                                   # same initial tables on every rank
-    user_emb = torch.empty((U, D), device=device).normal_(std=0.1 / D)
-    item_emb = torch.empty((I, D), device=device).normal_(std=0.1 / D)
-    item_bias = torch.empty((I,), device=device).normal_(std=0.1)
-    indptr, indices = csr.to_device(device)
-    coo_u = torch.from_numpy(data.train[:, 0].astype(np.int32)).to(device)
-    coo_i = torch.from_numpy(data.train[:, 1].astype(np.int32)).to(device)
-    st = ShardedBprMf(comm, user_emb, item_emb, item_bias, lr=LR, wd=WD, batch=B, n_neg=N, csr_indptr=indptr,
-                      csr_indices=indices, coo_user=coo_u, coo_item=coo_i, seed=seed)
-    del user_emb
-    return st, csr, comm
+def build_sharded_state(data, D, B, N, device, comm, seed=64):
+    """world > 1: item table range-sharded, user table row-sharded (hassaku_amd/dist.py); B positives per rank."""
+    from hassaku_amd.dist import ShardedBprMf
+    csr, arrays = device_interactions(data, device)
+    user_emb, item_emb, item_bias = init_tables(data.n_users, data.n_items, D, device, seed)   # same on every rank
+    st = ShardedBprMf(comm, user_emb, item_emb, item_bias, lr=LR, wd=WD, batch=B, n_neg=N, seed=seed, **arrays)
+    del user_emb, item_emb, item_bias
+    return st, csr
 
 
-def hip_stage_names(st):
-    from hassaku_amd.hip_ops import BprMfFusedState
-    return BprMfFusedState.STAGES if isinstance(st, BprMfFusedState) else ('fwd', 'item')
+# ------------------------------------------------------------------------------------------------
+# one training workload
+# ------------------------------------------------------------------------------------------------
+def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy_users=True, all_stages=False):
+    """-> dict(value, ms_per_step, fwd_us, fwd_launches, loss, B, N, D, data, csr, timing).  Timed exactly as the
+    contract says: W warm-up steps, barrier + synchronize, K steps (+ the flush of lazily updated rows), barrier +
+    synchronize; MAX over ranks."""
+    from hassaku_amd.data import synthetic
+    shape, D, N, B = WORKLOADS[workload]
+    world = 1 if comm is None else comm.world
+    data = synthetic.generate_named(shape, seed=0)          # same seed on every rank: identical data everywhere
+    nnz = data.train.shape[0]
+    if comm is None:
+        st, csr = build_state(data, D, B, N, device, overlap=prefetch, lazy_users=lazy_users)
+    else:
+        st, csr = build_sharded_state(data, D, B, N, device, comm)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(64)
+    order = torch.randperm(nnz, device=device, generator=gen)
+    if comm is not None:
+        comm.broadcast(order, src=0)                              # one epoch order for the whole job
+    G = B * world
+    n_batches = nnz // G
+
+    def run(n, first):
+        if comm is None:
+            # the epoch's inner loop, issued from C in runs of consecutive batches (hsk_bprmf_train_steps: each step
+            # hints the next one to the prefetch); a run ends where the epoch order wraps around
+            s = 0
+            while s < n:
+                k0 = (first + s) % n_batches
+                m = min(n - s, n_batches - k0, 256)
+                st.steps_sampled(order, k0 * B, m, B, N)
+                s += m
+            return
+        for s in range(n):
+            start = ((first + s) % n_batches) * G                # global batch = world * B positives (weak scaling)
+            nxt = ((first + s + 1) % n_batches) * G if s + 1 < n else None
+            st.step_sampled(order, start, next_start=nxt)
+
+    def fence():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    run(warmup, 0)
+    fence()
+    st.check_status('warm-up')
+    # every stage on every step when asked; otherwise only the roofline kernel, on every 8th step (every step for short
+    # runs), so that the event records (each costs a few us of launch gap) do not distort the step time being measured
+    names = ('prep', 'scan', 'scatter', 'fwd', 'item', 'user', 'finish') if comm is None else ('fwd', 'item', 'user')
+    st.enable_timing(names if all_stages else ('fwd',), every=1 if (all_stages or steps < 64) else 8)
+    fence()
+    t0 = time.perf_counter()
+    run(steps, warmup)
+    st.flush()   # lazily updated rows are brought up to date INSIDE the timed region: no work is skipped
+    fence()
+    elapsed = time.perf_counter() - t0
+    st.disable_timing()
+    if comm is not None:                                          # the slowest rank defines the step time
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        comm.all_reduce(t, op='max')
+        elapsed = float(t.item())
+    timing = st.collect_timing()
+    st.check_status('timed region')
+    loss = st.last_loss()
+    assert np.isfinite(loss), loss
+    fwd_ms, fwd_n = timing.get('fwd', (float('nan'), 0))
+    out = dict(value=steps * B * N * world / elapsed, ms_per_step=elapsed * 1e3 / steps,
+               fwd_us=(fwd_ms * 1e3 / fwd_n) if fwd_n else None, fwd_launches=int(fwd_n), loss=loss, B=B, N=N, D=D,
+               data=data, csr=csr, nnz=nnz, steps=steps, warmup=warmup)
+    if all_stages:
+        out['stage_us_per_step'] = {k: v[0] * 1e3 / max(v[1], 1) for k, v in timing.items()}
+    del st
+    torch.cuda.empty_cache()
+    return out
 
 
+def workload_name(workload, r):
+    d = r['data']
+    return (f'{workload}-shaped synthetic, mf + bpr + adamw, embedding_dim={r["D"]}, neg_train={r["N"]}, '
+            f'batch={r["B"]}, U={d.n_users}, I={d.n_items}, nnz_train={r["nnz"]}')
+
+
+def roofline_of(workload, r):
+    """Roofline object of the gather+BPR kernel for one workload.  `bound` names what the gathered tables sit in."""
+    if not r['fwd_us']:
+        return None
+    by = fwd_read_bytes(r['B'], r['N'], r['D'])
+    achieved = by / (r['fwd_us'] * 1e-6) / 1e9
+    d = r['data']
+    table_mb = 4.0 * r['D'] * d.n_items / 1e6
+    cached = table_mb < 200.0          # 256 MiB Infinity Cache
+    traffic, src = pmc_traffic('k_fwd_ugrad', workload)
+    out = {'bound': 'infinity-cache' if cached else 'hbm',
+           'kernel': 'k_fwd_ugrad (gather + scores + BPR + user-row grad)',
+           'achieved': achieved, 'unit': 'GB/s',
+           'peak': ICACHE_GATHER_GBS if cached else HBM_PEAK_GBS,
+           'frac': achieved / (ICACHE_GATHER_GBS if cached else HBM_PEAK_GBS),
+           'peak_source': ('MI355X_MICROARCH.md: 8.6 TB/s measured for uniformly random row gathers from an Infinity-Cache-'
+                           'resident table (the %.1f MB item table is cache-resident; FETCH_SIZE counts cache hits, so true '
+                           'HBM bytes of this kernel are not observable)' % table_mb) if cached else
+                          'MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (guide measures 6.29 TB/s streaming, 5.7-5.8 TB/s for random 2.3 KB rows)',
+           'frac_of_hbm_spec_8000': achieved / HBM_PEAK_GBS,
+           'traffic': traffic, 'traffic_source': src,
+           'avg_us': r['fwd_us'], 'launches': r['fwd_launches'], 'algorithmic_bytes_per_launch': by,
+           'item_table_MB': table_mb}
+    if not cached:
+        out['frac_of_measured_hbm_gather_5750'] = achieved / HBM_GATHER_GBS
+    # the metric's own roofline: whole step against algorithmic gather bytes at the HBM spec peak (SURVEY 8d)
+    out['step_frac_of_hbm_roofline'] = r['value'] / (HBM_PEAK_GBS * 1e9 / (by / (r['B'] * r['N'])))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation legs
+# ------------------------------------------------------------------------------------------------
+class _EvalData:
+    """Synthetic exclusion / ground-truth CSRs of one evaluation shape (what a FullEvalDataset exposes)."""
+
+    def __init__(self, U, I, npos, device):
+        from hassaku_amd.data.csr import UserItemCsr
+        rng = np.random.default_rng(0)
+        users = np.repeat(np.arange(U), npos)
+        self.exclude_csr = UserItemCsr.from_pairs(users, rng.integers(0, I, size=len(users)), U, I)
+        self.label_csr = UserItemCsr.from_pairs(np.repeat(np.arange(U), 10), rng.integers(0, I, size=10 * U), U, I)
+        self.n_users, self.n_items = U, I
+        lp, li = self.label_csr.to_device(device)
+        ep, ei = self.exclude_csr.to_device(device)
+        self._arr = {'label_indptr': lp, 'label_indices': li, 'excl_indptr': ep, 'excl_indices': ei}
+
+    def device_arrays(self, device):
+        return self._arr
+
+
+def run_eval(shape, device, comm=None, chunk=2048, repeat=3):
+    """Full-catalogue evaluation (scores U x I^T, exclusion mask, top-100, precision/recall/ndcg at 100/50/10/5).
+    comm None: one GPU.  Otherwise ITEM-SHARDED over the ranks on physically sliced tables (dist.evaluate_item_sharded)."""
+    from hassaku_amd import hip_ops as ops
+    from hassaku_amd.eval.eval import FullEvaluator
+    U, I, D, npos = EVAL_SHAPES[shape]
+    torch.manual_seed(0)
+    user_emb = torch.randn(U, D, device=device) * 0.05
+    item_emb = torch.randn(I, D, device=device) * 0.05
+    item_bias = torch.randn(I, device=device) * 0.1
+    ds = _EvalData(U, I, npos, device)
+    ev = FullEvaluator(aggr_by_group=True, n_groups=0, user_to_user_group=None)
+    ks = sorted(ev.K_VALUES, reverse=True)
+    world = 1 if comm is None else comm.world
+    if comm is None:
+        arr = ds.device_arrays(device)
+        scores = torch.empty((chunk, I), dtype=torch.float32, device=device)
+
+        def one_pass():
+            acc = torch.zeros((len(ks), 3), dtype=torch.float64, device=device)
+            for lo in range(0, U, chunk):
+                u = torch.arange(lo, min(lo + chunk, U), device=device)
+                _, ids, _ = ops.mf_eval_topk(user_emb, item_emb, item_bias, None, None, u, ks[0], arr['excl_indptr'],
+                                             arr['excl_indices'], scores_ws=scores)
+                acc += ops.rank_metrics(ids, u, arr['label_indptr'], arr['label_indices'], ks).double().sum(0)
+            return {f'ndcg@{k}': float(acc[t, 2] / U) for t, k in enumerate(ks)}
+    else:
+        from hassaku_amd.dist import TableShards, evaluate_item_sharded
+        shards = TableShards.cut(comm, user_emb, item_emb, item_bias)
+        del user_emb, item_emb, item_bias
+
+        chunk = min(chunk * world, U)     # a rank scores chunk x I/world: the per-rank GEMM stays the single-GPU size
+
+        def one_pass():
+            return evaluate_item_sharded(comm, shards, ds, ev, chunk=chunk)
+
+    check = one_pass()                # warm-up
+    torch.cuda.synchronize()
+    if comm is not None:
+        comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(repeat):
+        one_pass()
+    torch.cuda.synchronize()
+    if comm is not None:
+        comm.barrier()
+    dt = (time.perf_counter() - t0) / repeat
+    if comm is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        comm.all_reduce(t, op='max')
+        dt = float(t.item())
+    tf = 2.0 * U * I * D / dt / 1e12
+    return {'workload': f'{shape}-shaped full evaluation: U={U}, I={I}, D={D}, top-100 + metrics at 100/50/10/5, '
+                        f'{npos} excluded positives per user, chunks of {chunk} users',
+            'n_gpus': world, 'sharding': 'items (range-sharded tables, candidate all_to_all)' if comm is not None else 'none',
+            'users_per_s': U / dt, 'seconds_per_full_eval': dt, 'tflops_fp32': tf,
+            'frac_of_fp32_mfma_peak_157': tf / (MFMA_FP32_TFLOPS * world), 'ndcg@10_check': check['ndcg@10']}
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------
 def usable_cores():
     """CPU share of this process: affinity mask, capped by the cgroup quota (a GPU box hands out 16 of its cores)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -117,28 +326,62 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(data, csr, D, N, B, budget_s):
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(headline, budget_s):
+    """oracle/cpu_trainer.py (kind "port") on the host cores, BEFORE the process touches the GPU (the 4-worker leg
+    forks loader processes).  Headline: a bounded sample of the ml10m workload.  Legs: SURVEY 8(d)'s protocol on
+    configs[0] (ml100k shape, D=64, N=1, B=128): 20 warm-up + 200 timed steps with 0 and with 4 loader workers."""
+    from hassaku_amd.data import synthetic
+    from hassaku_amd.data.csr import UserItemCsr
     from oracle.cpu_trainer import CpuTrainer
     cores = usable_cores()
-    tr = CpuTrainer(data.n_users, data.n_items, D, LR, WD, csr.indptr, csr.indices, data.train[:, 0], data.train[:, 1],
-                    N, B, threads=cores)
+
+    def trainer(workload):
+        shape, D, N, B = WORKLOADS[workload]
+        data = synthetic.generate_named(shape, seed=0)
+        csr = UserItemCsr.from_pairs(data.train[:, 0], data.train[:, 1], data.n_users, data.n_items)
+        return CpuTrainer(data.n_users, data.n_items, D, LR, WD, csr.indptr, csr.indices, data.train[:, 0],
+                          data.train[:, 1], N, B, threads=cores), D, N, B
+
+    legs = []
+    tr, D, N, B = trainer('ml100k')
+    for workers in (0, 4):
+        steps, secs = tr.time_loader_steps(workers=workers, warmup=20, steps=200)
+        legs.append({'workload': f'configs[0]: ml100k shape, D={D}, N={N}, B={B}', 'train_n_workers': workers,
+                     'warmup': 20, 'steps': steps, 'seconds': secs, 'value': steps * B * N / secs, 'unit': 'triplets/s'})
+    tr, D, N, B = trainer(headline)
     steps, secs = tr.time_steps(budget_s=budget_s)
-    return {'value': steps * B * N / secs, 'unit': 'triplets/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{steps} steps of B={B} x N={N} (D={D}) in {secs:.1f}s, torch CPU + numpy sampler, 0 workers'}
+    return {'value': steps * B * N / secs, 'unit': 'triplets/s', 'cores': cores, 'cpu_model': cpu_model(),
+            'kind': 'port',
+            'sample': f'{steps} steps of B={B} x N={N} (D={D}, {headline} shape) in {secs:.1f}s, torch CPU ops on '
+                      f'{cores} threads + numpy rejection sampler, 0 loader workers',
+            'legs': legs}
 
 
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='ml10m', choices=sorted(WORKLOADS))
-    ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU-baseline work (0 = skip)')
+    ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of CPU-baseline work on the headline workload (0 = skip every CPU leg)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' "
                     "stages collectives through the host and lets several ranks share one GPU: functional rehearsal only)")
     ap.add_argument('--no-prefetch', action='store_true', help='do not prepare (sample + sort) the next batch on a side stream during the current step')
     ap.add_argument('--dense-users', action='store_true', help='dense AdamW sweep over the user table every step')
     ap.add_argument('--time-all-stages', action='store_true', help='event-time every stage (perturbs the step time)')
+    ap.add_argument('--only', action='store_true', help='headline workload only: no extra workloads, no eval legs')
+    ap.add_argument('--sharded', action='store_true', help='N=1 through the multi-GPU code path (1-rank process group)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -146,112 +389,68 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+
+    cpu = None
+    if world == 1 and args.cpu_budget > 0:
+        cpu = cpu_baseline(args.workload, args.cpu_budget)        # before anything initialises the GPU
+
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if world > 1:
+    comm = None
+    if world > 1 or args.sharded:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        from hassaku_amd.dist import Comm
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(args.backend)
+        comm = Comm()
 
-    from hassaku_amd.data import synthetic
-    shape, D, N, B = WORKLOADS[args.workload]
-    data = synthetic.generate_named(shape, seed=0)          # same seed on every rank: identical data everywhere
-    nnz = data.train.shape[0]
-    comm = None
-    if world == 1:
-        st, csr = build_state(data, D, B, N, device, overlap=not args.no_prefetch, lazy_users=not args.dense_users)
-    else:
-        st, csr, comm = build_sharded_state(data, D, B, N, device)
-
-    gen = torch.Generator(device=device)
-    gen.manual_seed(64)
-    order = torch.randperm(nnz, device=device, generator=gen)
-    if comm is not None:
-        comm.broadcast(order, src=0)                              # one epoch order for the whole job
-    n_batches = nnz // (B * world)
-
-    def run(n, first):
-        if world == 1:
-            # the epoch's inner loop, issued from C in runs of consecutive batches (hsk_bprmf_train_steps: each step
-            # hints the next one to the prefetch); a run ends where the epoch order wraps around
-            s = 0
-            while s < n:
-                k0 = (first + s) % n_batches
-                m = min(n - s, n_batches - k0, 256)
-                st.steps_sampled(order, k0 * B, m, B, N)
-                s += m
-            return
-        for s in range(n):
-            start = ((first + s) % n_batches) * B * world        # global batch = world * B positives (weak scaling)
-            st.step_sampled(order, start)
-
-    def fence():
-        if comm is not None:
-            comm.barrier()
-        torch.cuda.synchronize()
-
-    run(args.warmup, 0)
-    fence()
-    st.check_status('warm-up')
-    # every stage on every step when asked; otherwise only the roofline kernel, on every 8th step, so that the
-    # event records (each costs a few us of launch gap) do not distort the step time being measured
-    stages = hip_stage_names(st) if args.time_all_stages else ('fwd',)
-    st.enable_timing(stages, every=1 if args.time_all_stages else 8)
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    st.flush()   # lazily updated user rows are brought up to date INSIDE the timed region: no work is skipped
-    fence()
-    t1 = time.perf_counter()
-    st.disable_timing()
-    elapsed = t1 - t0
-    if comm is not None:                                          # the slowest rank defines the step time
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    timing = st.collect_timing()
-    st.check_status('timed region')
-    loss = st.last_loss()
-    assert np.isfinite(loss), loss
-
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = args.steps * B * N * world / elapsed
-    fwd_ms, fwd_n = timing['fwd']
-    fwd_us = fwd_ms * 1e3 / fwd_n
-    achieved = fwd_read_bytes(B, N, D) / (fwd_us * 1e-6) / 1e9
+    r = run_training(args.workload, device, args.steps, args.warmup, comm=comm, prefetch=not args.no_prefetch,
+                     lazy_users=not args.dense_users, all_stages=args.time_all_stages)
     out = {
-        'metric': 'BPR triplets/sec', 'value': value, 'unit': 'triplets/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'metric': 'BPR triplets/sec', 'value': r['value'], 'unit': 'triplets/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{args.workload}-shaped synthetic, mf + bpr + adamw, embedding_dim={D}, '
-                               f'neg_train={N}, batch={B}, U={data.n_users}, I={data.n_items}, nnz_train={nnz}',
-                   'global_batch': B * world,
-                   'parallelism': 'single GPU' if world == 1 else
-                   f'{world} ranks: user tables row-sharded (all_to_all), item table replicated (all_reduce)',
-                   'lr': LR, 'wd': WD,
-                   'loss_last_step': loss},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_fwd_ugrad (gather + scores + BPR + user-row grad)',
-                     'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': pmc_traffic_bytes('k_fwd_ugrad', PROFILE_DIR) if args.workload == 'ml10m' else None,
-                     'traffic_source': f'profiles/{PROFILE_DIR}/pmc_summary.json (rocprofv3 --pmc, same command)',
-                     'avg_us': fwd_us, 'launches': fwd_n,
-                     'algorithmic_bytes_per_launch': fwd_read_bytes(B, N, D)},
+        'config': {'workload': workload_name(args.workload, r), 'global_batch': r['B'] * world,
+                   'parallelism': 'single GPU' if comm is None else
+                   f'item-sharded: {world} rank(s), item table range-sharded + user table row-sharded; all_gather of '
+                   f'user rows, reduce_scatter of user-row gradients, 2 scalar-per-positive all_reduces; no table is replicated',
+                   'lr': LR, 'wd': WD, 'loss_last_step': r['loss']},
+        'roofline': roofline_of(args.workload, r),
     }
-    if args.time_all_stages:
-        out['stage_us_per_step'] = {k: v[0] * 1e3 / args.steps for k, v in timing.items()}
-    if rank == 0 and world == 1 and args.cpu_budget > 0:
-        out['cpu_baseline'] = cpu_baseline(data, csr, D, N, B, args.cpu_budget)
+    if comm is not None:
+        out['roofline']['kernel'] = 'k_shard_fwd (gather of the owned negatives + scores + BPR + partial user-row grad)'
+    if 'stage_us_per_step' in r:
+        out['stage_us_per_step'] = r['stage_us_per_step']
+
+    if not args.only:
+        if comm is None:
+            # the other BASELINE training configs + the HBM-resident point, each on the same clock as the headline
+            out['workloads'] = {}
+            for name, (k, w) in (('ml1m', (2000, 200)), ('ml100k', (2000, 200)), ('hbm', (64, 16))):
+                if name == args.workload:
+                    continue
+                x = run_training(name, device, k, w)
+                out['workloads'][name] = {
+                    'workload': workload_name(name, x), 'value': x['value'], 'unit': 'triplets/s', 'steps': k,
+                    'warmup': w, 'ms_per_step': x['ms_per_step'], 'loss_last_step': x['loss'],
+                    'roofline': roofline_of(name, x)}
+            out['eval'] = {s: run_eval(s, device) for s in ('ml10m', 'lfm2b')}
+        else:
+            out['eval'] = {'lfm2b': run_eval('lfm2b', device, comm)}
+    if cpu is not None:
+        out['cpu_baseline'] = cpu
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if comm is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

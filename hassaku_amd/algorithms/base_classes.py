@@ -70,6 +70,9 @@ class SGDBasedRecommenderAlgorithm(RecommenderAlgorithm, nn.Module):
         return self(u_idxs, i_idxs)
 
     def save_model_to_path(self, path: str):
+        hook = getattr(self, '_pre_save_hook', None)   # a fused trainer registers its flush(): no lazily updated row
+        if callable(hook):                             # reaches the checkpoint with pending zero-gradient steps
+            hook()
         torch.save(self.state_dict(), os.path.join(path, 'model.pth'))
         logging.info('Model Saved')
 

@@ -180,7 +180,14 @@ class SGDMatrixFactorization(SGDBasedRecommenderAlgorithm):
     @torch.no_grad()
     def _score_all(self, u_idxs: torch.Tensor, i_idxs: torch.Tensor) -> torch.Tensor:
         n = i_idxs.numel()
-        full = n == self.n_items and bool((i_idxs[0] == 0) & (i_idxs[-1] == n - 1))
+        # whole catalogue in catalogue order?  Decided by comparing with arange (any permutation takes the general
+        # path); the verdict is remembered per index tensor, so an evaluation loop syncs once, not once per batch
+        key = (i_idxs.data_ptr(), n, i_idxs._version)
+        if getattr(self, '_full_key', None) != key:
+            self._full_key = key
+            self._full_val = n == self.n_items and bool(
+                torch.equal(i_idxs, torch.arange(n, dtype=i_idxs.dtype, device=i_idxs.device)))
+        full = self._full_val
         user_emb, item_emb, ib, ub, gb = self.tables()
         if full:
             _, _, scores = hip_ops.mf_eval_topk(user_emb, item_emb, ib, ub, gb, u_idxs.contiguous(), 0,

@@ -774,8 +774,14 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
 extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
   int rc = hsk_check_state(st);
   if (rc) return rc;
-  if (!st->lazy_users && !st->lazy_items) return HSK_OK;  // dense updates: nothing is pending
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  // a flush ends a run of steps (epoch end, evaluation, checkpoint): a hinted or prefetched batch that was never
+  // trained on must not survive it -- the next epoch's permutation may well be allocated at the same address
+  if (st->aux) {
+    ((hsk_aux*)st->aux)->hint_valid = false;
+    if ((rc = hsk_discard_prefetch(st, w, (hipStream_t)stream_))) return rc;
+  }
+  if (!st->lazy_users && !st->lazy_items) return HSK_OK;  // dense updates: nothing is pending
   return hsk_launch_flush(st, w, (hipStream_t)stream_);
 }
 

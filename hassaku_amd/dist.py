@@ -463,17 +463,46 @@ class ShardedBprMf:
         return gather(self.item_emb), (None if self.item_bias is None else gather(self.item_bias))
 
 
+class TableShards:
+    """This rank's share of a trained model (what the item-sharded evaluation reads): users u % W == r at row u // W,
+    items item_range(I, r, W).  ShardedBprMf offers the same attributes."""
+
+    def __init__(self, comm, user_emb, item_emb, item_bias, user_bias, global_bias, n_users, n_items):
+        self.comm, self.device = comm, user_emb.device
+        self.user_emb, self.item_emb, self.item_bias, self.user_bias = user_emb, item_emb, item_bias, user_bias
+        self.global_bias = global_bias
+        self.n_users_global, self.n_items, self.dim = int(n_users), int(n_items), user_emb.shape[1]
+        self.item_lo, self.item_hi = item_range(self.n_items, comm.rank, comm.world)
+        if item_emb.shape[0] != self.item_hi - self.item_lo or \
+                user_emb.shape[0] != local_user_count(self.n_users_global, comm.rank, comm.world):
+            raise ValueError('shard shapes do not match the ownership rule')
+
+    @staticmethod
+    def cut(comm, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None):
+        """Shards of FULL tables that are identical on every rank."""
+        W, r = comm.world, comm.rank
+        lo, hi = item_range(item_emb.shape[0], r, W)
+        return TableShards(comm, user_emb[r::W].contiguous(), item_emb[lo:hi].contiguous(),
+                           None if item_bias is None else item_bias.reshape(-1)[lo:hi].contiguous(),
+                           None if user_bias is None else user_bias.reshape(-1)[r::W].contiguous(), global_bias,
+                           user_emb.shape[0], item_emb.shape[0])
+
+    def flush(self):
+        pass
+
+
 # ------------------------------------------------------------------------------------------------
 # item-sharded full evaluation (BASELINE configs[3])
 # ------------------------------------------------------------------------------------------------
-def evaluate_item_sharded(comm: Comm, sharded: ShardedBprMf, dataset, evaluator, chunk: int = 2048):
+def evaluate_item_sharded(comm: Comm, sharded, dataset, evaluator, chunk: Optional[int] = None):
     """Full evaluation on the sharded tables (eval/eval.py:237-253 + FullEvaluator of the reference).  Per chunk of
     users: (1) the owners all_gather the chunk's user rows; (2) every rank scores the chunk against ITS item shard --
     `hsk_mf_eval_topk` over the physical slice, exclusion mask restricted to its range -- and keeps a local top-k with
     global item ids; (3) the candidates of user j go to the rank that merges j (all_to_all, k*8 bytes per user and
     rank), which runs `hsk_topk_merge` and the rank metrics for its share of the chunk; (4) per-group sums and counts
     are all-reduced once at the end.  The candidate exchange of a chunk runs under the scoring of the next one.
-    `dataset` is a FullEvalDataset (its CSRs are global); `evaluator` supplies K_VALUES and the user groups."""
+    `sharded` is a ShardedBprMf or a TableShards; `dataset` a FullEvalDataset (its CSRs are global); `evaluator`
+    supplies K_VALUES and the user groups."""
     sharded.flush()
     W, r = comm.world, comm.rank
     dev = sharded.device
@@ -490,6 +519,8 @@ def evaluate_item_sharded(comm: Comm, sharded: ShardedBprMf, dataset, evaluator,
     sums = torch.zeros((n_groups + 1, len(ks), 3), dtype=torch.float64, device=dev)
     counts = torch.zeros(n_groups + 1, dtype=torch.float64, device=dev)
     status = hip_ops.new_status(dev)
+    if chunk is None:        # a rank scores chunk x I/W: 2048*W users per chunk keep its GEMM the size of one GPU's
+        chunk = min(2048 * W, U)
     chunk = max(W, (int(chunk) + W - 1) // W * W)         # chunk boundaries at multiples of W: a rank's rows of a chunk
     S = chunk // W                                         # are a contiguous slice of its shard; S users merged per rank
     scores = torch.empty((chunk, I_loc), dtype=torch.float32, device=dev)

@@ -276,8 +276,10 @@ def sample_negatives_uniform(csr_indptr, csr_indices, n_items, u_idx, n_neg, see
 class BprMfFusedState:
     """Owns the torch tensors the C `hsk_bprmf_state` points at (moments, workspace, loss, status).
 
-    Parameters are borrowed from the model (`nn.Parameter.data`), so state_dict()/model.pth see
-    every update.  One instance per (model, optimizer hyper-parameters).
+    Parameters are borrowed from the model (`nn.Parameter.data`): the fused step writes into the model's own
+    tensors.  With the lazy AdamW (lazy_users, the default; lazy_items on large catalogues) a row outside the batch
+    keeps up to 63 pending zero-gradient steps until it is next touched: call flush() before reading the tables
+    (state_dict(), save_model_to_path(), evaluation) -- Trainer does.  One instance per (model, hyper-parameters).
     """
 
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,

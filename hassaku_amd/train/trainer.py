@@ -68,6 +68,7 @@ class Trainer:
             self.optimizer = None
         elif want_fused and fusable:
             self.fused = self._build_fused(conf)
+            self.pointer_to_model._pre_save_hook = self.fused.flush
             self.optimizer = None
         else:
             # autograd path (any SGD model / loss): forward, loss and backward are HIP autograd functions, and the

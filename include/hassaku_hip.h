@@ -278,7 +278,8 @@ int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, int64_t start
 int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t n_steps, int64_t batch,
                           int64_t n_neg, hsk_stream_t stream);
 
-/* Bring lazily-updated user rows up to st->step (no-op when lazy_users == 0). */
+/* Bring lazily-updated user / item rows up to st->step (no-op with dense updates); also drops a pending hint and a
+ * prefetched batch that was never trained on (a flush ends a run of steps). */
 int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
 
 /* Copy of the device batch the last *_sampled step used (debug / parity): u [batch], items [batch,n_cols] */

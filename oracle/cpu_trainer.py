@@ -56,6 +56,26 @@ def bpr_loss(out, labels):
     return nn.BCEWithLogitsLoss()(diff.flatten(), tgt)
 
 
+class _PairDataset(torch.utils.data.Dataset):
+    """(user, item) of interaction k -- TrainRecDataset.__getitem__ (data/dataset.py:133-140 of the reference)."""
+
+    def __init__(self, coo_user, coo_item):
+        self.coo_user, self.coo_item = coo_user, coo_item
+
+    def __len__(self):
+        return len(self.coo_user)
+
+    def __getitem__(self, k):
+        return self.coo_user[k], self.coo_item[k]
+
+
+def _loader_collate(batch, indptr, indices, n_items, n_neg):
+    """TrainDataLoader._neg_sampling_collate_fn (data/dataloader.py:92-129): runs inside the loader worker, global numpy RNG"""
+    u = np.array([b[0] for b in batch], dtype=np.int64)
+    pos = np.array([b[1] for b in batch], dtype=np.int64)
+    return _collate(np.random, u, pos, indptr, indices, n_items, n_neg)
+
+
 class CpuTrainer:
     def __init__(self, n_users, n_items, dim, lr, wd, indptr, indices, coo_user, coo_item, n_neg, batch, seed=64,
                  threads=None):
@@ -84,6 +104,31 @@ class CpuTrainer:
         u, items, labels = _collate(self.rng, self.coo_user[sel], self.coo_item[sel], self.indptr, self.indices,
                                     self.n_items, self.n_neg)
         return self.step_on(u, items, labels)
+
+    def time_loader_steps(self, workers=0, warmup=20, steps=200):
+        """SURVEY 8(d) protocol: the reference's loader shape -- a shuffling torch DataLoader whose collate_fn draws the
+        negatives, `workers` worker processes with prefetch_factor 2 (data/data_utils.py:335-343) -- feeding the same
+        step; `warmup` untimed steps, then `steps` timed ones.  -> (steps, seconds)"""
+        import functools
+        from torch.utils.data import DataLoader
+        collate = functools.partial(_loader_collate, indptr=self.indptr, indices=self.indices, n_items=self.n_items,
+                                    n_neg=self.n_neg)
+        kw = dict(num_workers=workers, prefetch_factor=2, persistent_workers=True) if workers else {}
+        loader = DataLoader(_PairDataset(self.coo_user, self.coo_item), batch_size=self.batch, shuffle=True,
+                            collate_fn=collate, **kw)
+        n, t0, done = 0, None, False
+        while not done:
+            for u, items, labels in loader:
+                if n == warmup:
+                    t0 = time.perf_counter()
+                self.step_on(u, items, labels)
+                n += 1
+                if n == warmup + steps:
+                    done = True
+                    break
+        secs = time.perf_counter() - t0
+        del loader
+        return steps, secs
 
     def time_steps(self, budget_s=15.0, min_steps=2, max_steps=200):
         """-> (steps, seconds) for a bounded sample of the workload (first step is an untimed warm-up)."""
