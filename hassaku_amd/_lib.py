@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhassaku_hip.so')
+LIB_PATH = os.environ.get('HSK_LIB_PATH') or os.path.join(_HERE, 'libhassaku_hip.so')   # override: A/B builds
 
 _lib = None
 
@@ -37,7 +37,7 @@ class HskBprmfState(ctypes.Structure):
         ('timing_every', c_int32), ('timing_now', c_int32),
         ('loss_kind', c_int32), ('opt_kind', c_int32), ('ssm_log_adjust', c_double),
         ('alias_prob', c_void_p), ('alias_idx', c_void_p),
-        ('lazy_items', c_int32), ('reserved2', c_int32),
+        ('lazy_items', c_int32), ('graph_chunk', c_int32),
         ('loss_out', c_void_p), ('status', c_void_p),
     ]
 
@@ -82,6 +82,8 @@ SIGNATURES = {
                                              c_void_p]),
     'hsk_bprmf_train_steps': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64, c_int64,
                                       c_void_p]),
+    'hsk_bprmf_last_sort': (c_int, [POINTER(HskBprmfState), c_int64, c_void_p, c_void_p, c_void_p]),
+    'hsk_bprmf_graph_replays': (c_int64, [POINTER(HskBprmfState)]),
     'hsk_timing_create': (c_void_p, []),
     'hsk_timing_destroy': (None, [c_void_p]),
     'hsk_timing_collect': (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),

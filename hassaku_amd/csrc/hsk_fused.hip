@@ -40,10 +40,15 @@ struct hsk_ws {
   int* cnt;
   int* last_step;
   float* dUb;
+  float *ucur, *mcur, *vcur;   // [max_batch, D] each: the batch's user rows (and, for rows that were behind, their
+                               // replayed moments) as the forward saw them (lazy user AdamW)
   double* loss_b;
   float2* adam_tab;
+  hsk_step_desc* desc;     // device-resident step descriptor of a replayed graph (hsk_rows.h)
   int *dupcnt, *duplist;   // per owner entry: how many / which further entries name the same user
   int* last_step_i;        // lazy item AdamW: steps already applied to each item row
+  int *stamp, *stamp_b;    // per buffer set: stamp[u] = step the set's batch is trained on (for its users)
+  int* claim;              // ahead-of-time catch-up: last step at which a row was claimed
   int *touched, *n_touched, *touched_b, *n_touched_b;   // per buffer set: items with entries (compact), their count
   // second set of the per-batch buffers: the next batch is sampled and sorted into it while this one trains
   int *u32_b, *it32_b, *perm_b, *hist_b, *btot_b, *bstart_b, *offsets_b, *owner_b, *cnt_b;
@@ -65,6 +70,7 @@ static inline hsk_ws hsk_select(const hsk_ws& w, int set) {
   std::swap(r.offsets, r.offsets_b);
   std::swap(r.owner, r.owner_b);
   std::swap(r.cnt, r.cnt_b);
+  std::swap(r.stamp, r.stamp_b);
   std::swap(r.touched, r.touched_b);
   std::swap(r.n_touched, r.n_touched_b);
   return r;
@@ -95,11 +101,18 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.cnt = (int*)take(n_users * 4);
   w.last_step = (int*)take(n_users * 4);
   w.dUb = (float*)take(max_batch * dim * 4);
+  w.ucur = (float*)take(max_batch * dim * 4);
+  w.mcur = (float*)take(max_batch * dim * 4);
+  w.vcur = (float*)take(max_batch * dim * 4);
   w.loss_b = (double*)take(max_batch * 8);
   w.adam_tab = (float2*)take((HSK_ADAM_TAB_LEN + 1) * sizeof(float2));
+  w.desc = (hsk_step_desc*)take(256);
   w.dupcnt = (int*)take(max_batch * 4);
   w.duplist = (int*)take(max_batch * HSK_DUP_MAX * 4);
   w.last_step_i = (int*)take(n_items * 4);
+  w.stamp = (int*)take(n_users * 4);
+  w.stamp_b = (int*)take(n_users * 4);
+  w.claim = (int*)take(n_users * 4);
   w.touched = (int*)take(ent * 4);
   w.touched_b = (int*)take(ent * 4);
   w.n_touched = (int*)take(256);
@@ -181,6 +194,9 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   HSK_HIP(hipMemsetAsync(w.cnt, 0, st->n_users * 4, stream));
   HSK_HIP(hipMemsetAsync(w.cnt_b, 0, st->n_users * 4, stream));
   HSK_HIP(hipMemsetAsync(w.dupcnt, 0, st->max_batch * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.stamp, 0, st->n_users * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.stamp_b, 0, st->n_users * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.claim, 0, st->n_users * 4, stream));
   HSK_HIP(hipMemsetAsync(w.n_touched, 0, 4, stream));
   HSK_HIP(hipMemsetAsync(w.n_touched_b, 0, 4, stream));
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_items, 256), 256, 0, stream>>>(w.last_step_i, st->n_items, (int)st->step);
@@ -285,6 +301,8 @@ static inline void hsk_stage_mark(const hsk_bprmf_state* st, int stage, bool beg
 // same sort.
 struct hsk_aux {
   hipStream_t side = nullptr;
+  hipStream_t cap = nullptr;   // graphs are captured on this stream (the caller's may be the legacy default stream,
+                               // which cannot be captured) and replayed on the caller's
   hipEvent_t ev_fork = nullptr, ev_ready = nullptr;
   bool hint_valid = false;
   const int64_t* hint_order = nullptr;
@@ -293,15 +311,29 @@ struct hsk_aux {
   const int64_t* pf_order = nullptr;
   int64_t pf_start = 0, pf_batch = 0, pf_nneg = 0, pf_step = 0;
   int cur_set = 0;  // buffers of the batch of the latest step
+  // graph capture context: while `g_desc` is set the launch sequence is being CAPTURED, not run: kernels take their
+  // per-step scalars from the device descriptor + the relative step `g_rel`, launches carry no events of their own
+  const hsk_step_desc* g_desc = nullptr;
+  int g_rel = 0;
+  struct graph_entry {
+    hipGraphExec_t exec;
+    int64_t n_steps, batch, n_neg;
+    int set0, flags;
+  };
+  std::vector<graph_entry> graphs;
+  bool graph_broken = false;   // a capture failed once: stay with eager launches
+  int64_t graph_launches = 0;  // replayed runs so far (hsk_bprmf_graph_replays)
 };
 
 extern "C" void hsk_aux_destroy(void* a_) {
   hsk_aux* a = (hsk_aux*)a_;
   if (!a) return;
   if (a->side) (void)hipStreamSynchronize(a->side);
+  for (auto& g : a->graphs) (void)hipGraphExecDestroy(g.exec);
   if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
   if (a->ev_ready) (void)hipEventDestroy(a->ev_ready);
   if (a->side) (void)hipStreamDestroy(a->side);
+  if (a->cap) (void)hipStreamDestroy(a->cap);
   delete a;
 }
 
@@ -315,6 +347,7 @@ extern "C" void* hsk_aux_create(void) {
   const char* pe = getenv("HSK_SIDE_PRIO");
   const int prio = pe ? atoi(pe) : prio_hi;
   bool ok = hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, prio) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&a->cap, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreate(&a->ev_fork) == hipSuccess;   // a kernel stop event: must be able to take a timestamp
   ok = ok && hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -385,10 +418,12 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
 // alignment allows (256 floats per slice at D % 4 == 0: two slices at D=512, each served by 4 XCDs whose L2 then
 // holds 4096 x 1 KB of user rows; measured 72 us against 93 us for whole rows).  Odd D: whole-row kernel.
 // `Urows` / `urow_index`: where the batch's user rows live (the table + u32, or the exchange buffer + slot_of_b).
+// `ua` (optional, APPLY only): the owners' user-row update rides in the same launch (k_item_user), see hsk_item_sliced.h.
 template <int V, int NCH, bool FULL, int R, bool APPLY>
 static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, const float* Urows, const int* urow_index,
                                  int K, const hsk_adamw_consts& c, float* gI_out, float* gIb_out, hipStream_t stream,
-                                 int64_t n_entries = 0) {
+                                 int64_t n_entries = 0, const hsk_user_lazy_args* ua = nullptr,
+                                 const hsk_ahead_args* aa = nullptr) {
   const int I = (int)st->n_items, D = (int)st->dim;
   if (D % 2 != 0) {
     k_item_update<V, NCH, FULL, R, APPLY><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
@@ -396,35 +431,51 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
         urow_index, w.g_s, w.perm, w.offsets, I, K, D, c, gI_out, gIb_out);
     return;
   }
-  const int vs = (D % 4 == 0) ? 4 : 2;
+  static const int force_vs = getenv("HSK_ITEM_VS") ? atoi(getenv("HSK_ITEM_VS")) : 0;      // tuning knobs
+  static const int ipw = getenv("HSK_ITEM_IPW") ? atoi(getenv("HSK_ITEM_IPW")) : 1;
+  const int vs = force_vs == 2 ? 2 : (D % 4 == 0) ? 4 : 2;
   const int n_sl = (int)hsk_ceil_div(D, 64 * vs);
   const int n_slices_pad = (n_sl < 8 && 8 % n_sl == 0) ? n_sl : (int)hsk_align_up(n_sl, 8);
-  const unsigned groups = (unsigned)hsk_align_up(hsk_ceil_div(I, 4), 8);
-#define HSK_ITEM_SLICED(VS, GEN)                                                                               \
-  k_item_update_sliced<APPLY, VS, GEN><<<groups * n_slices_pad, 256, 0, stream>>>(                              \
-      Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,     \
-      urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, 1, c, gI_out, gIb_out)
+  const bool lazy = APPLY && st->lazy_items;
+  // lazy item AdamW: only the items with entries (the sort's `touched` list; at most one per entry)
+  const int64_t n_list = lazy ? std::min<int64_t>(I, n_entries) : I;
+  const unsigned groups = (unsigned)hsk_align_up(hsk_ceil_div(n_list, 4 * ipw), 8);
+  const hsk_item_args ia = {Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias,
+                            st->v_item_bias, urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, ipw, c,
+                            gI_out, gIb_out, w.touched, w.n_touched, w.last_step_i, (int)st->step,
+                            ua ? ua->desc : nullptr, ua ? ua->rel : 0, w.adam_tab, HSK_ADAM_TAB_LEN};
   const bool gen = APPLY && st->opt_kind != HSK_OPT_ADAMW;   // APPLY == false never calls the update
-  if (APPLY && st->lazy_items) {
-    // lazy item AdamW: only the items with entries (the sort's `touched` list; at most one per entry)
-    const unsigned lgroups = (unsigned)hsk_align_up(hsk_ceil_div(std::min<int64_t>(I, n_entries), 4), 8);
-#define HSK_ITEM_SLICED_LAZY(VS, GEN)                                                                          \
-  k_item_update_sliced<APPLY, VS, GEN, true><<<lgroups * n_slices_pad, 256, 0, stream>>>(                       \
-      Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,     \
-      urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, 1, c, gI_out, gIb_out, w.touched,            \
-      w.n_touched, w.last_step_i, (int)st->step)
+  const unsigned nblk = groups * n_slices_pad;
+  if (APPLY && ua) {
+    const int dense = ua->n_users > 0;
+    const int nub = (int)hsk_align_up(hsk_ceil_div(dense ? ua->n_users : ua->B, 4) + 1, 8);
+    const hsk_ahead_args ahead = aa ? *aa : hsk_ahead_args{};
+    // ahead workgroups (4 entries each) in octets, one after every `stride` octets of item workgroups; what does not
+    // fit that pattern is dropped (the forward replays those rows itself)
+    const int item_oct = (int)(nblk / 8);
+    int n_ahead_oct = ahead.coo_user ? (int)hsk_ceil_div(hsk_ceil_div(ahead.n, 4), 8) : 0;
+    n_ahead_oct = std::min(n_ahead_oct, item_oct);
+    const int stride = n_ahead_oct ? item_oct / n_ahead_oct : 0;
+#define HSK_ITEM_USER(VS, GEN, LZ)                                                                              \
+  k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)(nub + 8 * n_ahead_oct), 256, 0, stream>>>(            \
+      ia, *ua, nub, dense, ahead, n_ahead_oct, stride)
     if (vs == 4) {
-      if (gen) HSK_ITEM_SLICED_LAZY(4, true); else HSK_ITEM_SLICED_LAZY(4, false);
+      if (gen) { if (lazy) HSK_ITEM_USER(4, true, true); else HSK_ITEM_USER(4, true, false); }
+      else     { if (lazy) HSK_ITEM_USER(4, false, true); else HSK_ITEM_USER(4, false, false); }
     } else {
-      if (gen) HSK_ITEM_SLICED_LAZY(2, true); else HSK_ITEM_SLICED_LAZY(2, false);
+      if (gen) { if (lazy) HSK_ITEM_USER(2, true, true); else HSK_ITEM_USER(2, true, false); }
+      else     { if (lazy) HSK_ITEM_USER(2, false, true); else HSK_ITEM_USER(2, false, false); }
     }
-#undef HSK_ITEM_SLICED_LAZY
+#undef HSK_ITEM_USER
     return;
   }
+#define HSK_ITEM_SLICED(VS, GEN, LZ) k_item_update_sliced<APPLY, VS, GEN, LZ><<<nblk, 256, 0, stream>>>(ia)
   if (vs == 4) {
-    if (gen) HSK_ITEM_SLICED(4, true); else HSK_ITEM_SLICED(4, false);
+    if (gen) { if (lazy) HSK_ITEM_SLICED(4, true, true); else HSK_ITEM_SLICED(4, true, false); }
+    else     { if (lazy) HSK_ITEM_SLICED(4, false, true); else HSK_ITEM_SLICED(4, false, false); }
   } else {
-    if (gen) HSK_ITEM_SLICED(2, true); else HSK_ITEM_SLICED(2, false);
+    if (gen) { if (lazy) HSK_ITEM_SLICED(2, true, true); else HSK_ITEM_SLICED(2, true, false); }
+    else     { if (lazy) HSK_ITEM_SLICED(2, false, true); else HSK_ITEM_SLICED(2, false, false); }
   }
 #undef HSK_ITEM_SLICED
 }
@@ -439,19 +490,36 @@ static inline double hsk_loss_norm(int kind, double batch, double n_cols) {
 // device batch construction: positives order[start .. start+batch) + sampled negatives, owner map
 static int hsk_launch_prep_sample(const hsk_bprmf_state* st, const hsk_ws& w, const int64_t* order, int64_t start,
                                   int64_t batch, int64_t n_neg, uint64_t stream_id, hipStream_t stream) {
+  const hsk_aux* ax = (const hsk_aux*)st->aux;
+  const hsk_step_desc* desc = ax ? ax->g_desc : nullptr;
+  // capture: `stream_id` arrives as the relative step of the batch being prepared
   HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
                                 st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
                                 st->csr_indices, (int)st->n_items, st->seed, stream_id, w.u32, w.it32, w.owner, w.cnt,
-                                st->status, 0, hsk_alias{st->alias_prob, st->alias_idx}));
+                                st->status, 0, hsk_alias{st->alias_prob, st->alias_idx}, desc, desc ? (int)stream_id : 0,
+                                w.stamp));
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
+
+static inline bool hsk_capturing(const hsk_bprmf_state* st);
 
 // item sort of the entries in w.it32 -> w.perm / w.offsets
 // n_dev: optional device-side entry count (<= total, see hsk_sort_count)
 static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t total, hipStream_t stream,
                            const int* n_dev = nullptr) {
   const int I = (int)st->n_items;
+  if (hsk_sort_lds_fits(I, total)) {
+    // one workgroup, LDS cursors + per-item fix-up (see k_sort_lds)
+    const size_t lds = hsk_sort_lds_bytes(I);
+    if (lds > 65536 && !hsk_capturing(st))   // opt-in for > 64 KB of dynamic LDS (not a stream operation)
+      HSK_HIP(hipFuncSetAttribute((const void*)k_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HSK_STAGE(HSK_STAGE_SCATTER, (k_sort_lds<<<1, 1024, lds, stream>>>(w.it32, (int)total, I, w.perm, w.offsets,
+                                                                       st->lazy_items ? w.touched : nullptr,
+                                                                       st->lazy_items ? w.n_touched : nullptr, n_dev)));
+    HSK_LAUNCH_CHECK();
+    return HSK_OK;
+  }
   if (total <= 1024 * 8) {
     // one workgroup sorts the whole batch (see k_sort_small)
     int nbits = 1;
@@ -491,6 +559,11 @@ static int hsk_launch_sort(const hsk_bprmf_state* st, const hsk_ws& w, int64_t t
   return HSK_OK;
 }
 
+static inline bool hsk_capturing(const hsk_bprmf_state* st) {
+  const hsk_aux* a = (const hsk_aux*)st->aux;
+  return a && a->g_desc;
+}
+
 // a prefetched batch that the next call does not consume: give its owner map back
 static int hsk_discard_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, hipStream_t stream) {
   hsk_aux* a = (hsk_aux*)st->aux;
@@ -516,6 +589,7 @@ static bool hsk_pf_early(int64_t B) { return B < 2048; }
 static bool hsk_prefetch_wanted(const hsk_bprmf_state* st) {
   hsk_aux* aux = (hsk_aux*)st->aux;
   if (!aux || !aux->hint_valid) return false;
+  if (aux->g_desc) return true;   // inside a graph the fork / join are dependencies, not host calls
   if (aux->hint_batch * (aux->hint_nneg + 1) < HSK_PREFETCH_MIN_ENTRIES) {
     aux->hint_valid = false;  // a few hundred entries: the fork/join events cost more than the five tiny kernels
     return false;
@@ -533,7 +607,7 @@ static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set
   if (!fork_recorded) HSK_HIP(hipEventRecord(aux->ev_fork, stream));
   HSK_HIP(hipStreamWaitEvent(aux->side, aux->ev_fork, 0));
   int prc = hsk_launch_prep_sample(st, wn, aux->hint_order, aux->hint_start, aux->hint_batch, aux->hint_nneg,
-                                   (uint64_t)st->step, aux->side);
+                                   aux->g_desc ? (uint64_t)(aux->g_rel + 1) : (uint64_t)st->step, aux->side);
   if (!prc) prc = hsk_launch_sort(st, wn, aux->hint_batch * (aux->hint_nneg + 1), aux->side);
   if (prc) return prc;
   HSK_HIP(hipEventRecord(aux->ev_ready, aux->side));
@@ -572,44 +646,41 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       HSK_STAGE(HSK_STAGE_ITEM, (k_item_catch_up<2, true><<<nblk, 256, 0, stream>>>(
                                     st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias, st->m_item_bias,
                                     st->v_item_bias, w.touched, w.n_touched, w.last_step_i, D, (int)st->step, c,
-                                    w.adam_tab, HSK_ADAM_TAB_LEN)));
+                                    w.adam_tab, HSK_ADAM_TAB_LEN, aux ? aux->g_desc : nullptr, aux ? aux->g_rel : 0)));
     else
       HSK_STAGE(HSK_STAGE_ITEM, (k_item_catch_up<2, false><<<nblk, 256, 0, stream>>>(
                                     st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias, st->m_item_bias,
                                     st->v_item_bias, w.touched, w.n_touched, w.last_step_i, D, (int)st->step, c,
-                                    w.adam_tab, HSK_ADAM_TAB_LEN)));
+                                    w.adam_tab, HSK_ADAM_TAB_LEN, aux ? aux->g_desc : nullptr, aux ? aux->g_rel : 0)));
     HSK_LAUNCH_CHECK();
   }
   if (hsk_pf_early(B)) {
     int prc = hsk_launch_prefetch(st, w_all, set, stream);
     if (prc) return prc;
   }
-  // late fork: the fork event is the forward kernel's own completion signal
+  // late fork: the fork event is the forward kernel's own completion signal (an ordinary event record in a capture)
+  const bool capturing = aux && aux->g_desc;
+  const hsk_step_desc* gdesc = capturing ? aux->g_desc : nullptr;
+  const int grel = capturing ? aux->g_rel : 0;
   const bool late_fork = !hsk_pf_early(B) && hsk_prefetch_wanted(st);
-  hipEvent_t fork_ev = late_fork ? aux->ev_fork : nullptr;
+  hipEvent_t fork_ev = (late_fork && !capturing) ? aux->ev_fork : nullptr;
 
   int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
     constexpr int V = decltype(v_)::value;
     constexpr int NCH = decltype(n_)::value;
     constexpr bool FULL = decltype(f_)::value;
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
-    if (st->lazy_users) {
-      // the forward must read current rows: replay the missed zero-gradient steps of this batch's users first
-#define HSK_CATCH_UP(VV, GEN)                                                                                     \
-  HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<VV, GEN><<<(unsigned)B, 256, 0, stream>>>(                            \
-                                st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,      \
-                                st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,         \
-                                w.adam_tab, HSK_ADAM_TAB_LEN, w.dupcnt, w.duplist)))
-      if (D % 2 == 0) {
-        if (gen) HSK_CATCH_UP(2, true); else HSK_CATCH_UP(2, false);
-      } else {
-        if (gen) HSK_CATCH_UP(1, true); else HSK_CATCH_UP(1, false);
-      }
-#undef HSK_CATCH_UP
-    }
+    // lazy user AdamW: the forward replays the pending zero-gradient steps of its user row in registers and leaves
+    // the current row in ucur (no separate catch-up launch, no rewrite of the row before the owner's update)
     // The forward kernel is launched through hipExtLaunchKernelGGL, whose start / stop events are the dispatch's own
     // timestamps: on a timed step they ARE the stage timing (kernel time as rocprofv3 reports it, no barrier packets
     // around the launch); otherwise the stop event is the prefetch's fork event.
+    hsk_lazy_user_args lz = {};
+    if (st->lazy_users)
+      lz = hsk_lazy_user_args{st->m_user_emb, st->v_user_emb, w.last_step, w.owner, w.dupcnt, w.duplist, w.ucur,
+                              w.mcur, w.vcur, (int)st->step, gen ? 1 : 0, c, w.adam_tab, HSK_ADAM_TAB_LEN, gdesc, grel};
+    else if (D % 2 == 0)
+      lz.ucur = w.ucur;   // dense users in the item pass's launch: it reads the batch's rows from ucur
     hipEvent_t fwd_beg = nullptr, fwd_end = fork_ev;
     hsk_timing* tm = (hsk_timing*)st->timing;
     const bool time_fwd = tm && st->timing_now && ((st->timing_mask >> HSK_STAGE_FWD) & 1);
@@ -621,17 +692,29 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       tm->end[HSK_STAGE_FWD].push_back(fwd_end);
     }
 #define HSK_LAUNCH_FWD(LK)                                                                                          \
-  hipExtLaunchKernelGGL((k_fwd_ugrad<V, NCH, FULL, R, LK>), dim3((unsigned)hsk_ceil_div(B, 4)), dim3(256), 0, stream,  \
-                        fwd_beg, fwd_end, 0, (const float*)st->user_emb, (const float*)st->item_emb,                \
-                        (const float*)st->item_bias, (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D,      \
-                        inv_bn, (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b, (const int*)nullptr)
+  if (capturing)                                                                                                    \
+    hipLaunchKernelGGL((k_fwd_ugrad<V, NCH, FULL, R, LK>), dim3((unsigned)hsk_ceil_div(B, 4)), dim3(256), 0, stream,   \
+                       (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,         \
+                       (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, (float)st->ssm_log_adjust,  \
+                       w.g_s, w.dUb, w.loss_b, (const int*)nullptr, lz);                                            \
+  else                                                                                                              \
+    hipExtLaunchKernelGGL((k_fwd_ugrad<V, NCH, FULL, R, LK>), dim3((unsigned)hsk_ceil_div(B, 4)), dim3(256), 0, stream, \
+                          fwd_beg, fwd_end, 0, (const float*)st->user_emb, (const float*)st->item_emb,              \
+                          (const float*)st->item_bias, (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D,    \
+                          inv_bn, (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b, (const int*)nullptr, lz)
     // small batches: a workgroup per positive (hsk_fwd_small.h); the one-wave kernel would leave most SIMDs idle
     // and walk each positive's rows as a chain of memory latencies
 #define HSK_LAUNCH_FWD_WG(LK)                                                                                       \
-  hipExtLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK>), dim3((unsigned)B), dim3(256),                          \
-                        (unsigned)(4 * (size_t)D * sizeof(float)), stream, fwd_beg, fwd_end, 0,                      \
-                        (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,        \
-                        (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b)
+  if (capturing)                                                                                                    \
+    hipLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK>), dim3((unsigned)B), dim3(256),                           \
+                       (unsigned)(4 * (size_t)D * sizeof(float)), stream, (const float*)st->user_emb,               \
+                       (const float*)st->item_emb, (const float*)st->item_bias, (const int*)w.u32,                  \
+                       (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b, lz);                   \
+  else                                                                                                              \
+    hipExtLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK>), dim3((unsigned)B), dim3(256),                        \
+                          (unsigned)(4 * (size_t)D * sizeof(float)), stream, fwd_beg, fwd_end, 0,                    \
+                          (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,      \
+                          (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b, lz)
     const bool wg_fwd = B <= 1024 && st->loss_kind != HSK_LOSS_SSM && K >= 9;
     if (wg_fwd && st->loss_kind == HSK_LOSS_BCE) {
       HSK_LAUNCH_FWD_WG(HSK_LOSS_BCE);
@@ -652,7 +735,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   HSK_LAUNCH_CHECK();
 
   if (late_fork) {
-    const bool fork_on_kernel = !(st->timing && st->timing_now && ((st->timing_mask >> HSK_STAGE_FWD) & 1));
+    const bool fork_on_kernel = !capturing && !(st->timing && st->timing_now && ((st->timing_mask >> HSK_STAGE_FWD) & 1));
     int prc = hsk_launch_prefetch(st, w_all, set, stream, fork_on_kernel);
     if (prc) return prc;
   }
@@ -662,35 +745,59 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     constexpr int NCH = decltype(n_)::value;
     constexpr bool FULL = decltype(f_)::value;
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
-    HSK_STAGE(HSK_STAGE_ITEM, hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, st->user_emb, w.u32, (int)K, c, nullptr,
-                                                                          nullptr, stream, total));
-    if (st->lazy_users) {
-      // + one workgroup for the loss reduction / global bias (no separate finish launch in lazy mode)
-      const hsk_finish_args fin = {w.loss_b, (int)B, inv_bn_d, st->loss_out, st->global_bias, st->m_global_bias,
-                                   st->v_global_bias};
-#define HSK_USER_LAZY(GEN)                                                                                          \
-  HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, GEN><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>( \
-                                st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,        \
-                                st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,               \
-                                (int)st->step, c, fin, w.dupcnt, w.duplist)))
-      if (gen) HSK_USER_LAZY(true); else HSK_USER_LAZY(false);
-#undef HSK_USER_LAZY
+    // user update: the owners' rows (lazy: pending steps were replayed by the forward) or a dense sweep over the
+    // table; + one workgroup for the loss reduction / global bias.  Even D: in the item pass's own launch.
+    const hsk_finish_args fin = {w.loss_b, (int)B, inv_bn_d, st->loss_out, st->global_bias, st->m_global_bias,
+                                 st->v_global_bias};
+    const bool lazy = st->lazy_users != 0;
+    const hsk_user_lazy_args ua = {st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
+                                   st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,
+                                   (int)st->step, c, fin, w.dupcnt, w.duplist, lazy ? w.adam_tab : nullptr,
+                                   HSK_ADAM_TAB_LEN, w.ucur, w.mcur, w.vcur, lazy ? 0 : U, gdesc, grel, w.adam_tab,
+                                   HSK_ADAM_TAB_LEN};
+    const bool timed_apart = st->timing && st->timing_now &&
+                             (((st->timing_mask >> HSK_STAGE_ITEM) | (st->timing_mask >> HSK_STAGE_USER)) & 1);
+    if (D % 2 == 0 && !timed_apart) {
+      // lazy users, small batches: the NEXT batch (the prefetch's, or the pending hint's) gets its rows brought up to
+      // date by workgroups of this same launch (hsk_user_ahead_body).  A small step is a chain of latencies with the
+      // VALUs idle, and the replay leaves the head of the forward's critical path (ml1m shape: forward 20 -> 11 us).
+      // At B = 4096 every kernel is within reach of its issue limit and the replay costs its ~10 us of VALU time
+      // wherever it runs: measured 233 us per step with these workgroups in the item pass against 221 us with the
+      // replay inside the forward, so large batches keep it there.
+      hsk_ahead_args aa = {};
+      static const int ahead_on = getenv("HSK_AHEAD") ? atoi(getenv("HSK_AHEAD")) : 1;
+      if (lazy && aux && ahead_on && hsk_pf_early(B) && (aux->pf_valid || aux->hint_valid)) {
+        const bool pf = aux->pf_valid;
+        aa = hsk_ahead_args{st->coo_user, pf ? aux->pf_order : aux->hint_order, pf ? aux->pf_start : aux->hint_start,
+                            (int)(pf ? aux->pf_batch : aux->hint_batch), w.stamp, w.claim, st->user_emb, st->m_user_emb,
+                            st->v_user_emb, st->user_bias, st->m_user_bias, st->v_user_bias, w.last_step, D,
+                            (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN, gdesc, grel};
+      }
+      // the item pass reads the user rows from ucur, the user blocks rewrite the table: independent -> one launch
+      hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, w.ucur, nullptr, (int)K, c, nullptr, nullptr, stream, total, &ua,
+                                                  &aa);
     } else {
-      HSK_STAGE(HSK_STAGE_USER, (k_user_update<V, NCH, FULL, 0><<<(unsigned)hsk_ceil_div(U, 4), 256, 0, stream>>>(
-                                    st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
-                                    st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, U, (int)B, D, c, nullptr, nullptr)));
+      const bool from_ucur = lazy || D % 2 == 0;
+      HSK_STAGE(HSK_STAGE_ITEM, (hsk_launch_item_pass<V, NCH, FULL, R, true>(
+                                    st, w, from_ucur ? w.ucur : st->user_emb, from_ucur ? nullptr : w.u32, (int)K, c,
+                                    nullptr, nullptr, stream, total, nullptr)));
+      if (lazy) {
+        if (gen)
+          HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, true><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>(ua)));
+        else
+          HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, false><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>(ua)));
+      } else {
+        if (gen)
+          HSK_STAGE(HSK_STAGE_USER, (k_user_update_dense<V, NCH, FULL, true><<<(unsigned)hsk_ceil_div(U, 4) + 1, 256, 0, stream>>>(ua)));
+        else
+          HSK_STAGE(HSK_STAGE_USER, (k_user_update_dense<V, NCH, FULL, false><<<(unsigned)hsk_ceil_div(U, 4) + 1, 256, 0, stream>>>(ua)));
+      }
     }
     return HSK_OK;
   });
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
-  if (!st->lazy_users) {
-    HSK_STAGE(HSK_STAGE_FINISH, k_finish_step<<<1, 1024, 0, stream>>>(w.loss_b, (int)B, inv_bn_d, st->loss_out,
-                                                                       st->global_bias, st->m_global_bias,
-                                                                       st->v_global_bias, c));
-    HSK_LAUNCH_CHECK();
-  }
-  if ((st->lazy_users || st->lazy_items) && (st->step % HSK_FLUSH_EVERY) == 0) {
+  if (!capturing && (st->lazy_users || st->lazy_items) && (st->step % HSK_FLUSH_EVERY) == 0) {
     int frc = 0;
     HSK_STAGE(HSK_STAGE_USER, frc = hsk_launch_flush(st, w, stream));
     if (frc) return frc;
@@ -721,7 +828,7 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   const hsk_ws ws = hsk_select(w, set);
   HSK_STAGE(HSK_STAGE_PREP, k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
                                 u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, ws.u32,
-                                ws.it32, ws.owner, ws.cnt, st->status));
+                                ws.it32, ws.owner, ws.cnt, st->status, ws.stamp, (int)st->step + 1));
   HSK_LAUNCH_CHECK();
   return hsk_run_step(st, w, set, false, batch, n_cols, stream);
 }
@@ -754,13 +861,159 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   return hsk_run_step(st, w, set, false, batch, n_neg + 1, stream);
 }
 
+// =============================================================================================
+// replayed HIP graphs: the steady-state inner loop without the host
+// =============================================================================================
+// At the reference's usual batch sizes (128..512) a step is a handful of 3-20 us kernels and the host's ~10 HIP calls
+// per step (3-5 us each) are what bounds it.  A run of `chunk` consecutive steps is therefore CAPTURED once -- the same
+// launch sequence as the eager path, two streams, fork / join by events, the next batch prepared under the current
+// one -- and replayed with one hipGraphLaunch per chunk.  Whatever differs between two replays (batch offset, step
+// index -> RNG stream id and Adam bias corrections, permutation pointer) is read by the kernels from a device
+// descriptor (hsk_step_desc) that a one-thread kernel rewrites in front of each replay.  Same kernels, same order,
+// same arithmetic: results are bit-identical to the eager sequence.
+__global__ void k_set_desc(hsk_step_desc* d, long long start0, const int64_t* order, int step0) {
+  d->start0 = start0;
+  d->order = order;
+  d->step0 = step0;
+  d->pad = 0;
+}
+
+#define HSK_GRAPH_DEFAULT_CHUNK 64
+#define HSK_GRAPH_MAX_CACHED 8
+
+static int64_t hsk_graph_chunk(const hsk_bprmf_state* st) {
+  static const int env = getenv("HSK_GRAPH") ? atoi(getenv("HSK_GRAPH")) : 1;
+  if (!env || st->graph_chunk < 0) return 0;
+  const hsk_aux* a = (const hsk_aux*)st->aux;
+  if (!a || a->graph_broken) return 0;
+  if (st->timing && st->timing_mask) return 0;            // stage timing needs events between the launches
+  if (st->dim % 2 != 0) return 0;                         // the merged item + user launch carries the descriptor
+  if ((st->lazy_users || st->lazy_items) && !hsk_adam_tab_saturates(st)) return 0;
+  if (st->step + 2 * HSK_GRAPH_DEFAULT_CHUNK >= HSK_ADAM_TAB_LEN && !hsk_adam_tab_saturates(st)) return 0;
+  return st->graph_chunk > 0 ? st->graph_chunk : HSK_GRAPH_DEFAULT_CHUNK;
+}
+
+// capture `n` steps of `batch` positives starting (relative to the descriptor) at step 0, first buffer set `set0`
+static int hsk_capture_steps(hsk_bprmf_state* st, const hsk_ws& w, int64_t n, int64_t batch, int64_t n_neg, int set0,
+                             hipGraphExec_t* out) {
+  hsk_aux* aux = (hsk_aux*)st->aux;
+  hipStream_t stream = aux->cap;
+  const int64_t K = n_neg + 1, total = batch * K;
+  if (hsk_sort_lds_fits(st->n_items, total)) {
+    if (hsk_sort_lds_bytes(st->n_items) > 65536)
+      HSK_HIP(hipFuncSetAttribute((const void*)k_sort_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)hsk_sort_lds_bytes(st->n_items)));
+  } else if (total > 1024 * 8) {   // dynamic-LDS opt-in of the bucket sort: not a stream operation, do it before the capture
+    hsk_sort_plan plan;
+    HSK_REQUIRE(hsk_make_sort_plan((int)st->n_items, total, &plan) == 0, HSK_ERR_UNSUPPORTED, "item sort: n_items too large");
+    const size_t bucket_lds = ((size_t)(st->lazy_items ? 6 : 5) * plan.ipb + 2) * sizeof(int);
+    if (bucket_lds > 65536)
+      HSK_HIP(hipFuncSetAttribute((const void*)k_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds));
+  }
+  const int64_t step_saved = st->step;
+  const int set_saved = aux->cur_set;
+  const int timing_saved = st->timing_now;
+  st->timing_now = 0;
+  aux->g_desc = w.desc;
+  int rc = HSK_OK;
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    aux->g_desc = nullptr;
+    hsk_set_error("hipStreamBeginCapture failed");
+    return HSK_ERR_HIP;
+  }
+  int set = set0;
+  for (int64_t s = 0; s < n && rc == HSK_OK; ++s) {
+    aux->g_rel = (int)s;
+    bool sorted = true;
+    if (s == 0) {   // the run's first batch is prepared inside the graph, on the main stream
+      rc = hsk_launch_prep_sample(st, hsk_select(w, set), nullptr, 0, batch, n_neg, 0, stream);
+      sorted = false;
+    } else {
+      if (hipStreamWaitEvent(stream, aux->ev_ready, 0) != hipSuccess) rc = HSK_ERR_HIP;
+      aux->pf_valid = false;
+    }
+    if (rc == HSK_OK && s + 1 < n) {   // name the next batch: prepared on the side stream under this step
+      aux->hint_valid = true;
+      aux->hint_order = nullptr;
+      aux->hint_start = 0;
+      aux->hint_batch = batch;
+      aux->hint_nneg = n_neg;
+    }
+    if (rc == HSK_OK) rc = hsk_run_step(st, w, set, sorted, batch, K, stream);
+    set ^= 1;
+  }
+  const hipError_t e = hipStreamEndCapture(stream, &graph);
+  aux->g_desc = nullptr;
+  aux->g_rel = 0;
+  aux->hint_valid = false;
+  aux->pf_valid = false;
+  aux->cur_set = set_saved;
+  st->step = step_saved;
+  st->timing_now = timing_saved;
+  if (rc == HSK_OK && e != hipSuccess) {
+    hsk_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    rc = HSK_ERR_HIP;
+  }
+  if (rc == HSK_OK && hipGraphInstantiate(out, graph, nullptr, nullptr, 0) != hipSuccess) {
+    hsk_set_error("hipGraphInstantiate failed");
+    rc = HSK_ERR_HIP;
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  return rc;
+}
+
 extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t n_steps,
                                      int64_t batch, int64_t n_neg, hsk_stream_t stream_) {
   HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
   HSK_REQUIRE(n_steps >= 0 && batch > 0 && start >= 0 && start + n_steps * batch <= st->nnz, HSK_ERR_INVALID,
               "steps [%lld, +%lld x %lld) outside nnz %lld", (long long)start, (long long)n_steps, (long long)batch,
               (long long)st->nnz);
-  for (int64_t s = 0; s < n_steps; ++s) {
+  int64_t s = 0;
+  const int64_t chunk_max = hsk_graph_chunk(st);
+  if (chunk_max >= 2 && n_steps >= chunk_max) {
+    int rc = hsk_check_state(st);
+    if (rc) return rc;
+    HSK_REQUIRE(st->csr_indptr && st->csr_indices && st->coo_user && st->coo_item, HSK_ERR_INVALID,
+                "CSR/COO of the training interactions missing from the state");
+    if ((rc = hsk_check_batch(st, batch, n_neg + 1))) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    hsk_aux* aux = (hsk_aux*)st->aux;
+    const hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+    const int flags = (st->lazy_users ? 1 : 0) | (st->loss_kind << 1) | (st->opt_kind << 4) | (st->lazy_items ? 64 : 0);
+    while (n_steps - s >= chunk_max) {
+      const int64_t n = chunk_max;
+      if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
+      aux->hint_valid = false;
+      const int set0 = 0;   // the buffer sets are scratch: with no prepared batch pending a run may start with either
+      hipGraphExec_t exec = nullptr;
+      for (auto& g : aux->graphs)
+        if (g.n_steps == n && g.batch == batch && g.n_neg == n_neg && g.set0 == set0 && g.flags == flags) exec = g.exec;
+      if (!exec) {
+        if ((rc = hsk_capture_steps(st, w, n, batch, n_neg, set0, &exec))) {
+          aux->graph_broken = true;   // eager launches from here on (the error text stays available)
+          break;
+        }
+        if (aux->graphs.size() >= HSK_GRAPH_MAX_CACHED) {
+          (void)hipGraphExecDestroy(aux->graphs.front().exec);
+          aux->graphs.erase(aux->graphs.begin());
+        }
+        aux->graphs.push_back({exec, n, batch, n_neg, set0, flags});
+      }
+      k_set_desc<<<1, 1, 0, stream>>>(w.desc, (long long)(start + s * batch), order, (int)st->step);
+      HSK_LAUNCH_CHECK();
+      HSK_HIP(hipGraphLaunch(exec, stream));
+      aux->graph_launches += 1;
+      st->step += n;
+      aux->cur_set = (n & 1) ? set0 : (set0 ^ 1);
+      s += n;
+      // lazily updated rows: the periodic sweep that bounds the replay length closes every replayed run (the eager
+      // path sweeps at multiples of HSK_FLUSH_EVERY; the cadence is a speed matter, any replay length is exact)
+      if ((st->lazy_users || st->lazy_items) && (rc = hsk_launch_flush(st, w, stream))) return rc;
+    }
+  }
+  for (; s < n_steps; ++s) {
     if (st->aux && s + 1 < n_steps) {
       int hrc = hsk_bprmf_hint_next(st, order, start + (s + 1) * batch, batch, n_neg);
       if (hrc) return hrc;
@@ -769,6 +1022,11 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
     if (rc) return rc;
   }
   return HSK_OK;
+}
+
+extern "C" int64_t hsk_bprmf_graph_replays(const hsk_bprmf_state* st) {
+  const hsk_aux* a = st ? (const hsk_aux*)st->aux : nullptr;
+  return a ? a->graph_launches : 0;
 }
 
 extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
@@ -797,6 +1055,20 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
                                                                                       u_out, i_out);
   HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+extern "C" int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries, int32_t* perm_out, int32_t* offsets_out,
+                                   hsk_stream_t stream_) {
+  int rc = hsk_check_state(st);
+  if (rc) return rc;
+  HSK_REQUIRE(perm_out && offsets_out && n_entries > 0 && n_entries <= st->max_batch * st->max_cols, HSK_ERR_INVALID,
+              "bad argument");
+  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set);
+  HSK_HIP(hipMemcpyAsync(perm_out, w.perm, n_entries * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+  HSK_HIP(hipMemcpyAsync(offsets_out, w.offsets, (st->n_items + 1) * sizeof(int), hipMemcpyDeviceToDevice,
+                         (hipStream_t)stream_));
   return HSK_OK;
 }
 

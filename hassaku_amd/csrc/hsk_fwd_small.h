@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad_wg(const float* __restrict__ 
                                                       const float* __restrict__ Ib, const int* __restrict__ u32,
                                                       const int* __restrict__ it32, int B, int K, int D,
                                                       float inv_norm, float* __restrict__ g_s,
-                                                      float* __restrict__ dUb, double* __restrict__ loss_b) {
+                                                      float* __restrict__ dUb, double* __restrict__ loss_b,
+                                                      hsk_lazy_user_args lz = hsk_lazy_user_args{}) {
   extern __shared__ float lds_rows[];   // [4][D]: partial gradient rows of waves 1..3 (slot 0 unused)
   __shared__ float sh_gsum[4];
   __shared__ double sh_loss[4];
@@ -32,6 +33,12 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad_wg(const float* __restrict__ 
   Row ur, r0, acc;
   hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
   hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  // lazily updated user row: every wave replays the pending steps on its own copy (identical results), wave 0
+  // publishes the current row for the item pass
+  if (lz.mU)
+    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, sub == 0);
+  else if (lz.ucur && sub == 0)
+    hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
   hsk_row_zero(acc);
   const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
 

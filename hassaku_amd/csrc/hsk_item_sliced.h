@@ -9,31 +9,83 @@
 // D=512, resident in its L2.  Same bytes, L2 rate instead of Infinity-Cache rate.
 #pragma once
 #include "hsk_rows.h"
+#include "hsk_step_kernels.h"
 
-template <bool APPLY, int VS, bool GEN, bool LAZY = false>   // VS floats per lane: slice width = 64*VS floats; GEN: see
-                                                            // hsk_adamw_update; LAZY: only the items in `touched`
-__global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restrict__ Uw, float* __restrict__ Iw,
-                                                            float* __restrict__ Ib, float* __restrict__ mI,
-                                                            float* __restrict__ vI, float* __restrict__ mIb,
-                                                            float* __restrict__ vIb, const int* __restrict__ u32,
-                                                            const float* __restrict__ g_s, const int* __restrict__ perm,
-                                                            const int* __restrict__ offsets, int n_items, int K, int D,
-                                                            int n_slices_pad, int items_per_wave, hsk_adamw_consts c,
-                                                            float* __restrict__ gI_out, float* __restrict__ gIb_out,
-                                                            const int* __restrict__ touched = nullptr,
-                                                            const int* __restrict__ n_touched = nullptr,
-                                                            int* __restrict__ last_step_i = nullptr, int step = 0) {
+#ifndef HSK_ITEM_MLP
+#define HSK_ITEM_MLP 8     // user-row loads a wave keeps in flight
+#endif
+#ifndef HSK_ITEM_NT
+#define HSK_ITEM_NT 0      // 1: the item rows (p, m, v: read once, written once per step) move with non-temporal hints
+#endif
+template <int VS>
+__device__ __forceinline__ hsk_vec<VS> hsk_ldg_stream(const float* p) {
+#if HSK_ITEM_NT
+  hsk_vec<VS> r;
+#pragma unroll
+  for (int i = 0; i < VS; ++i) r.v[i] = __builtin_nontemporal_load(p + i);
+  return r;
+#else
+  return hsk_ldg<VS>(p);
+#endif
+}
+template <int VS>
+__device__ __forceinline__ void hsk_stg_stream(float* p, const hsk_vec<VS>& x) {
+#if HSK_ITEM_NT
+#pragma unroll
+  for (int i = 0; i < VS; ++i) __builtin_nontemporal_store(x.v[i], p + i);
+#else
+  hsk_stg<VS>(p, x);
+#endif
+}
+
+struct hsk_item_args {
+  const float* Uw;        // user rows: the table (+ u32), an exchange buffer (+ slot index) or ucur (u32 == NULL)
+  float* Iw; float* Ib; float* mI; float* vI; float* mIb; float* vIb;
+  const int* u32;         // row of Uw for batch position e / K; NULL: the position itself
+  const float* g_s; const int* perm; const int* offsets;
+  int n_items, K, D, n_slices_pad, items_per_wave;
+  hsk_adamw_consts c;
+  float* gI_out; float* gIb_out;
+  const int* touched; const int* n_touched; int* last_step_i; int step;   // LAZY only
+  const hsk_step_desc* desc; int rel;   // graph replay: step = desc->step0 + rel + 1, c from ctab
+  const float2* ctab; int ctab_len;
+};
+
+// VS floats per lane: slice width = 64*VS floats; GEN: see hsk_adamw_update; LAZY: only the items in `touched`.
+// `bid` = workgroup index inside the item pass (the launch may carry other workgroups in front, see k_item_user).
+template <bool APPLY, int VS, bool GEN, bool LAZY>
+__device__ __forceinline__ void hsk_item_sliced_body(const hsk_item_args& a, int bid) {
+  const float* __restrict__ Uw = a.Uw;
+  float* __restrict__ Iw = a.Iw;
+  float* __restrict__ Ib = a.Ib;
+  float* __restrict__ mI = a.mI;
+  float* __restrict__ vI = a.vI;
+  float* __restrict__ mIb = a.mIb;
+  float* __restrict__ vIb = a.vIb;
+  const int* __restrict__ u32 = a.u32;
+  const float* __restrict__ g_s = a.g_s;
+  const int* __restrict__ perm = a.perm;
+  const int* __restrict__ offsets = a.offsets;
+  const int n_items = a.n_items, K = a.K, D = a.D, n_slices_pad = a.n_slices_pad, items_per_wave = a.items_per_wave;
+  hsk_adamw_consts c = a.c;
+  int step = a.step;
+  hsk_resolve_step(a.desc, a.rel, a.ctab, a.ctab_len, step, c);
+  float* __restrict__ gI_out = a.gI_out;
+  float* __restrict__ gIb_out = a.gIb_out;
+  const int* __restrict__ touched = a.touched;
+  const int* __restrict__ n_touched = a.n_touched;
+  int* __restrict__ last_step_i = a.last_step_i;
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   // n_slices_pad = number of slices when it divides 8 (each slice then owns 8/n XCDs), else a multiple of 8
   int slice, group;
   if (n_slices_pad < 8) {
-    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int xcd = bid & 7, r = bid >> 3;
     slice = xcd % n_slices_pad;
     group = r * (8 / n_slices_pad) + xcd / n_slices_pad;
   } else {
-    slice = blockIdx.x % n_slices_pad;
-    group = blockIdx.x / n_slices_pad;
+    slice = bid % n_slices_pad;
+    group = bid / n_slices_pad;
   }
   constexpr int SW = 64 * VS;
   const int d = slice * SW + lane * VS;
@@ -52,9 +104,9 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
     // AdamW operands early: their latency hides under the gather
     hsk_vec<VS> p = hsk_zero<VS>(), m = hsk_zero<VS>(), v = hsk_zero<VS>();
     if (APPLY && live) {
-      p = hsk_ldg<VS>(Iw + (long long)i * D + d);
-      m = hsk_ldg<VS>(mI + (long long)i * D + d);
-      v = hsk_ldg<VS>(vI + (long long)i * D + d);
+      p = hsk_ldg_stream<VS>(Iw + (long long)i * D + d);
+      m = hsk_ldg_stream<VS>(mI + (long long)i * D + d);
+      v = hsk_ldg_stream<VS>(vI + (long long)i * D + d);
     }
     hsk_vec<VS> acc = hsk_zero<VS>();
     float gb_lane = 0.f;
@@ -65,17 +117,17 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
       if (lane < nr) {
         const int e = perm[c0 + lane];
         myg = g_s[e];
-        myu = u32[e / K];
+        myu = u32 ? u32[e / K] : e / K;   // NULL: user rows are laid out by batch position (ucur)
       }
       gb_lane += myg;
-      for (int j = 0; j < nr; j += 8) {
-        hsk_vec<VS> val[8];
+      for (int j = 0; j < nr; j += HSK_ITEM_MLP) {
+        hsk_vec<VS> val[HSK_ITEM_MLP];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+        for (int r = 0; r < HSK_ITEM_MLP; ++r)
           val[r] = (j + r < nr && live) ? hsk_ldg<VS>(Uw + (long long)hsk_readlane_i(myu, min(j + r, 63)) * D + d)
                                         : hsk_zero<VS>();
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+        for (int r = 0; r < HSK_ITEM_MLP; ++r)
           if (j + r < nr) {
             const float g = hsk_readlane_f(myg, j + r);
 #pragma unroll
@@ -87,9 +139,9 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
       if (live) {
 #pragma unroll
         for (int q = 0; q < VS; ++q) hsk_adamw_update<GEN>(p.v[q], m.v[q], v.v[q], acc.v[q], c);
-        hsk_stg<VS>(Iw + (long long)i * D + d, p);
-        hsk_stg<VS>(mI + (long long)i * D + d, m);
-        hsk_stg<VS>(vI + (long long)i * D + d, v);
+        hsk_stg_stream<VS>(Iw + (long long)i * D + d, p);
+        hsk_stg_stream<VS>(mI + (long long)i * D + d, m);
+        hsk_stg_stream<VS>(vI + (long long)i * D + d, v);
       }
       if (slice == 0 && Ib) {
         const float gbias = hsk_wave_sum(gb_lane);
@@ -110,4 +162,47 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(const float* __restr
       }
     }
   }
+}
+
+template <bool APPLY, int VS, bool GEN, bool LAZY = false>
+__global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
+  hsk_item_sliced_body<APPLY, VS, GEN, LAZY>(a, (int)blockIdx.x);
+}
+
+// The item pass and the owners' user-row update in ONE launch: the first n_user_blocks workgroups (a multiple of 8, so
+// that the item workgroups keep their XCD affinity) are k_user_update_lazy's, the rest k_item_update_sliced's.  The two
+// are independent once the item pass reads the batch's user rows from `ucur` instead of the table the owners rewrite:
+// one launch boundary less, and the short user workgroups finish under the item pass.
+// A third kind of workgroup is interleaved with the item pass's: n_ahead_oct OCTETS of hsk_user_ahead_body, bringing
+// the NEXT batch's user rows up to date under the item pass (hsk_step_kernels.h).  One octet of them follows every
+// `stride` octets of item workgroups (whole octets, so the item workgroups keep blockIdx % 8 == their own index % 8,
+// i.e. their XCD affinity): the replay is VALU work that should run beside the memory-bound item waves, not in front
+// of them.
+template <int V, int NCH, bool FULL, int VS, bool GEN, bool LAZYI>
+__global__ __launch_bounds__(256) void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks,
+                                                   int dense_users, hsk_ahead_args aa, int n_ahead_oct, int stride) {
+  const int bid = (int)blockIdx.x;
+  if (bid < n_user_blocks) {
+    if (dense_users)
+      hsk_user_update_dense_body<V, NCH, FULL, GEN>(ua, bid);
+    else
+      hsk_user_update_lazy_body<V, NCH, FULL, GEN>(ua, bid);
+    return;
+  }
+  const int q = (bid - n_user_blocks) >> 3, r = bid & 7;   // n_user_blocks is a multiple of 8
+  int item_oct = q;
+  if (n_ahead_oct > 0) {
+    const int period = stride + 1, full = n_ahead_oct * period;
+    if (q < full) {
+      const int k = q / period, j = q - k * period;
+      if (j == stride) {
+        hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, k * 8 + r);
+        return;
+      }
+      item_oct = k * stride + j;
+    } else {
+      item_oct = n_ahead_oct * stride + (q - full);
+    }
+  }
+  hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, item_oct * 8 + r);
 }

@@ -6,6 +6,17 @@
 
 #define HSK_OWNER_NONE 0x7fffffff
 
+// Device-resident step descriptor.  A replayed HIP graph has its kernel arguments frozen at capture time, so what
+// changes from one replay to the next -- where the run of batches starts, how many steps were applied before it (RNG
+// stream id, Adam bias corrections), the epoch permutation -- is read from here; a kernel of step `rel` of the run
+// adds its own (frozen) offset.  desc == NULL: the immediate arguments apply (eager launches).
+struct hsk_step_desc {
+  long long start0;        // position of the run's first batch in `order`
+  const int64_t* order;    // epoch permutation (NULL: identity)
+  int step0;               // optimiser steps applied before the run
+  int pad;
+};
+
 // ---------------------------------------------------------------------------------------------
 // dimension dispatch: V floats per lane per chunk, NCH chunks per row, FULL = no tail predicate
 // ---------------------------------------------------------------------------------------------

@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void k_prep_external(const int64_t* __restrict
                                                        int n_users, int n_items, int* __restrict__ u32,
                                                        int* __restrict__ it32,
                                                        int* __restrict__ owner, int* __restrict__ cnt,
-                                                       int32_t* status) {
+                                                       int32_t* status, int* __restrict__ stamp = nullptr,
+                                                       int stamp_val = 0) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * K;
   if (e < total) {
@@ -23,6 +24,7 @@ __global__ __launch_bounds__(256) void k_prep_external(const int64_t* __restrict
     u32[e] = u;
     atomicMin(&owner[u], (int)e);
     atomicAdd(&cnt[u], 1);
+    if (stamp) stamp[u] = stamp_val;
   }
 }
 
@@ -105,10 +107,18 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
                                                      int* __restrict__ it32,
                                                      int* __restrict__ owner, int* __restrict__ cnt,
                                                      int32_t* status, int b_offset = 0,
-                                                     hsk_alias at = hsk_alias{nullptr, nullptr}) {
-  // b_offset: position of this rank's slice inside the global batch.  The RNG counter uses the GLOBAL batch
-  // position, so N ranks with slices of B draw exactly what one device draws for a batch of N*B.
-  // owner == NULL: no owner map (row-sharded user tables build it on the owning rank instead).
+                                                     hsk_alias at = hsk_alias{nullptr, nullptr},
+                                                     const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0,
+                                                     int* __restrict__ stamp = nullptr) {
+  // stamp (optional): stamp[u] = the (1-based) step this batch is trained on, for every user of the batch -- how a
+  // kernel of that step tells the rows being updated from the rows it may bring up to date ahead of time
+  // b_offset: offset added to the batch position in the RNG counter (a slice of a larger global batch).
+  // owner == NULL: no owner map.  desc: graph replay, see hsk_step_desc.
+  if (desc) {
+    start = desc->start0 + (long long)rel * B;
+    order = desc->order;
+    stream_id = (uint64_t)(desc->step0 + rel);
+  }
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
       atomicMin(&owner[u], b);
       atomicAdd(&cnt[u], 1);
     }
+    if (stamp) stamp[u] = (int)stream_id + 1;
   }
 }
 

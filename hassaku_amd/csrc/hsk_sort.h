@@ -348,4 +348,130 @@ __global__ __launch_bounds__(1024) void k_sort_small(const int* __restrict__ it3
     for (int i = prev + 1; i <= n_items; ++i) offsets[i] = n_entries;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small batches over catalogues with few entries per item (<= 8192 entries, on average <= 4 per item): ONE workgroup
+// of 1024 threads, everything in LDS.  The block radix sort above spends ~34 us on 6 528 entries of 12-bit keys
+// (BASELINE configs[1]) -- by then the longest kernel of the step -- because every one of its passes moves every entry.
+// Here:   count per item (LDS atomics)  ->  scan over the items (16 waves)  ->  scatter through per-item LDS cursors.
+// The cursors hand out positions in whatever order the atomics land, so each item's short list is then put into
+// ascending entry order: lists of <= 8 entries by their own thread (registers, a fixed compare-exchange network),
+// longer ones by a wave (rank = number of smaller entries, counted from LDS).  The result is the stable sort by item,
+// bit for bit what the other two sorts produce.  LDS: 3 * n_items + 2 * 8192 + 64 ints (the second 8192 holds the
+// work list of long items; sized for the worst case).
+// ---------------------------------------------------------------------------------------------
+#define HSK_SORT_LDS_CAP 8192
+static inline size_t hsk_sort_lds_bytes(int64_t n_items) { return ((size_t)3 * n_items + 2 * HSK_SORT_LDS_CAP + 64) * sizeof(int); }
+#define HSK_SORT_LDS_MAX_ITEMS 8000   // 3 x n_items + 16 448 ints <= 160 KB
+// few entries per item on average: the per-item fix-up is what this sort adds to a plain scatter
+static inline bool hsk_sort_lds_fits(int64_t n_items, int64_t n_entries) {
+  return n_entries <= HSK_SORT_LDS_CAP && n_items <= HSK_SORT_LDS_MAX_ITEMS && n_entries <= 4 * n_items;
+}
+
+__device__ __forceinline__ void hsk_cswap(int& a, int& b) {
+  const int lo = min(a, b), hi = max(a, b);
+  a = lo;
+  b = hi;
+}
+
+__global__ __launch_bounds__(1024) void k_sort_lds(const int* __restrict__ it32, int n_entries, int n_items,
+                                                   int* __restrict__ perm, int* __restrict__ offsets,
+                                                   int* __restrict__ touched = nullptr,
+                                                   int* __restrict__ n_touched = nullptr,
+                                                   const int* __restrict__ n_dev = nullptr) {
+  n_entries = hsk_sort_count(n_entries, n_dev);
+  extern __shared__ int lds[];
+  const int I = n_items;
+  int* cnt = lds;                       // [I]  entries per item
+  int* beg = lds + I;                   // [I]  first position of the item's list
+  int* cur = lds + 2 * I;               // [I]  scatter cursor
+  int* tmp = lds + 3 * I;               // [CAP] entries, grouped by item
+  int* tmp2 = tmp + HSK_SORT_LDS_CAP;   // [CAP] items whose list is longer than 8 entries
+  int* meta = tmp2 + HSK_SORT_LDS_CAP;  // [0..15] wave totals, [16] touched count, [17] long-list count
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  constexpr int IPT = HSK_SORT_LDS_CAP / 1024;
+  int keys[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int e = j * 1024 + tid;
+    keys[j] = (e < n_entries) ? it32[e] : -1;
+  }
+  for (int j = tid; j < I; j += 1024) cnt[j] = 0;
+  if (tid < 64) meta[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < IPT; ++j)
+    if (keys[j] >= 0) atomicAdd(&cnt[keys[j]], 1);
+  __syncthreads();
+  // exclusive scan of cnt over the items: wave w owns a contiguous run of whole 64-item chunks
+  const int chunks = (I + 63) / 64, cpw = (chunks + 15) / 16;
+  const int c_lo = min(chunks, w * cpw), c_hi = min(chunks, (w + 1) * cpw);
+  int carry = 0;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int j = c * 64 + lane;
+    const int v = (j < I) ? cnt[j] : 0;
+    const int incl = hsk_wave_incl_scan(v, lane);
+    if (j < I) beg[j] = carry + incl - v;
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) meta[w] = carry;
+  __syncthreads();
+  int wbase = 0;
+  for (int ww = 0; ww < w; ++ww) wbase += meta[ww];
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int j = c * 64 + lane;
+    if (j < I) {
+      const int st = beg[j] + wbase;
+      beg[j] = st;
+      cur[j] = st;
+      offsets[j] = st;
+      if (touched && cnt[j] > 0) touched[atomicAdd(&meta[16], 1)] = j;
+    }
+  }
+  if (tid == 0) offsets[I] = n_entries;
+  __syncthreads();
+  if (touched && tid == 0) *n_touched = meta[16];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j)
+    if (keys[j] >= 0) tmp[atomicAdd(&cur[keys[j]], 1)] = j * 1024 + tid;
+  __syncthreads();
+  // short lists: one thread each, in registers
+  for (int j = tid; j < I; j += 1024) {
+    const int n = cnt[j];
+    if (n == 0) continue;
+    if (n > 8) {
+      tmp2[atomicAdd(&meta[17], 1)] = j;   // work list of the long-list pass (at most CAP/9 items)
+      continue;
+    }
+    const int st = beg[j];
+    int v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (q < n) ? tmp[st + q] : 0x7fffffff;
+    // optimal 19-exchange network for 8 keys
+    hsk_cswap(v[0], v[2]); hsk_cswap(v[1], v[3]); hsk_cswap(v[4], v[6]); hsk_cswap(v[5], v[7]);
+    hsk_cswap(v[0], v[4]); hsk_cswap(v[1], v[5]); hsk_cswap(v[2], v[6]); hsk_cswap(v[3], v[7]);
+    hsk_cswap(v[0], v[1]); hsk_cswap(v[2], v[3]); hsk_cswap(v[4], v[5]); hsk_cswap(v[6], v[7]);
+    hsk_cswap(v[2], v[4]); hsk_cswap(v[3], v[5]);
+    hsk_cswap(v[1], v[4]); hsk_cswap(v[3], v[6]);
+    hsk_cswap(v[1], v[2]); hsk_cswap(v[3], v[4]); hsk_cswap(v[5], v[6]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < n) perm[st + q] = v[q];
+  }
+  __syncthreads();
+  // long lists: one wave each; an entry's place = number of smaller entries of its list (they are distinct), counted
+  // from LDS (all lanes read the same word: a broadcast)
+  const int n_long = meta[17];
+  for (int t = w; t < n_long; t += 16) {
+    const int j = tmp2[t];
+    const int st = beg[j], n = cnt[j];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const int mine = (i < n) ? tmp[st + i] : 0x7fffffff;
+      int rank = 0;
+      for (int k = 0; k < n; ++k) rank += (tmp[st + k] < mine) ? 1 : 0;
+      if (i < n) perm[st + rank] = mine;
+    }
+  }
+}
+
 #endif  // __HIPCC__

@@ -2,6 +2,90 @@
 #pragma once
 #include "hsk_rows.h"
 
+__device__ __forceinline__ hsk_adamw_consts hsk_consts_at(const hsk_adamw_consts& base, const float2* __restrict__ tab,
+                                                          int tab_len, int t) {
+  hsk_adamw_consts c = base;
+  const float2 e = tab[min(t, tab_len)];   // (step_size, bc2_sqrt or its reciprocal, see hsk_fused.hip)
+  c.step_size = e.x;
+#if HSK_ADAM_IEEE
+  c.bc2_sqrt = e.y;
+#else
+  c.rbc2_sqrt = e.y;
+#endif
+  return c;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Lazy user rows inside the forward.  A user row outside the previous batches carries pending zero-gradient AdamW
+// steps (see "Lazy, exact user-table AdamW" below).  Instead of a separate catch-up launch that rewrites the row
+// before the forward reads it, the forward replays the missed steps IN REGISTERS on its own copy (p, m, v of the row:
+// two more row loads for the rows that are behind), scores with the current row and leaves it in `ucur[b]` for the
+// item pass.  The table itself is not touched here (duplicate entries of a user replay the same stale row and must
+// not see a half-rewritten one): the owner entry also leaves the replayed moments in `mcur[b]` / `vcur[b]`, and the
+// owner's update kernel picks the current (p, m, v) up from there instead of replaying again.  Non-owner entries of a
+// user (duplicates in the batch) register with the owner.
+// ---------------------------------------------------------------------------------------------
+struct hsk_lazy_user_args {
+  const float* mU;        // NULL: rows are current (dense user updates, or rows handed over by an exchange)
+  const float* vU;
+  const int* last_step;
+  const int* owner;
+  int* dupcnt;
+  int* duplist;
+  float* ucur;            // [B, D]: the batch's user rows as the scores saw them
+  float* mcur;            // [B, D]: replayed moments of the rows that were behind (owner entries only)
+  float* vcur;
+  int step;               // the step being taken
+  int gen;                // 1: generic optimiser arithmetic (adam / adagrad), 0: AdamW
+  hsk_adamw_consts c;
+  const float2* tab;
+  int tab_len;
+  const hsk_step_desc* desc;   // graph replay: step = desc->step0 + rel + 1
+  int rel;
+};
+
+#define HSK_DUP_MAX 8   // duplicate entries of one user that are listed for the owner (more: batch scan)
+
+template <int V, int NCH, bool FULL>
+__device__ __forceinline__ void hsk_user_row_current(hsk_row<V, NCH>& p, int u, int b, int B, int D, int lane,
+                                                     const hsk_lazy_user_args& lz, bool publish) {
+  const int step = lz.desc ? lz.desc->step0 + lz.rel + 1 : lz.step;
+  const int done = hsk_uniform_i(lz.last_step[u]);
+  const int own = hsk_uniform_i(lz.owner[u]);
+  if (done < step - 1) {
+    hsk_row<V, NCH> m, v;
+    hsk_row_load<V, NCH, FULL>(m, lz.mU + (long long)u * D, lane, D);
+    hsk_row_load<V, NCH, FULL>(v, lz.vU + (long long)u * D, lane, D);
+    for (int t = done + 1; t <= step - 1; ++t) {
+      const hsk_adamw_consts ct = hsk_consts_at(lz.c, lz.tab, lz.tab_len, t);
+      if (lz.gen) {
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+          for (int q = 0; q < V; ++q) hsk_adamw_replay<true>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+          for (int q = 0; q < V; ++q) hsk_adamw_replay<false>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+      }
+    }
+    if (publish && own == b) {
+      hsk_row_store<V, NCH, FULL>(m, lz.mcur + (long long)b * D, lane, D);
+      hsk_row_store<V, NCH, FULL>(v, lz.vcur + (long long)b * D, lane, D);
+    }
+  }
+  if (!publish) return;
+  hsk_row_store<V, NCH, FULL>(p, lz.ucur + (long long)b * D, lane, D);
+  if (lane == 0) {
+    if (own != b && own >= 0 && own < B) {   // a further entry of a user somebody else owns: tell the owner
+      const int slot = atomicAdd(&lz.dupcnt[own], 1);
+      if (slot < HSK_DUP_MAX) lz.duplist[own * HSK_DUP_MAX + slot] = b;
+    }
+  }
+}
+
 // =============================================================================================
 // K1: per positive b -- gather u row + (1+N) item rows, scores, BPR loss terms, d loss/d score,
 //     user-row gradient (accumulated in registers).  One wave per positive.
@@ -23,7 +107,8 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
                                                    const int* __restrict__ it32, int B, int K, int D,
                                                    float inv_norm, float ssm_c, float* __restrict__ g_s,
                                                    float* __restrict__ dUb, double* __restrict__ loss_b,
-                                                   const int* __restrict__ dU_index = nullptr) {
+                                                   const int* __restrict__ dU_index = nullptr,
+                                                   hsk_lazy_user_args lz = hsk_lazy_user_args{}) {
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
@@ -37,6 +122,10 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
   Row ur, r0, acc;
   hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
   hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  if (lz.mU)
+    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, true);
+  else if (lz.ucur)   // dense user updates: the rows are current; the item pass still reads them by batch position
+    hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
   hsk_row_zero(acc);
   const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
 
@@ -174,7 +263,7 @@ __global__ __launch_bounds__(256) void k_item_update(const float* __restrict__ U
     if (lane < nr) {
       const int e = perm[c0 + lane];
       myg = g_s[e];
-      myu = u32[e / K];
+      myu = u32 ? u32[e / K] : e / K;   // NULL: user rows are laid out by batch position (ucur)
     }
     gb_lane += myg;
 
@@ -238,7 +327,6 @@ __global__ __launch_bounds__(256) void k_item_update(const float* __restrict__ U
 //     MODE 0: dense AdamW sweep over all rows (one wave per table row)
 //     MODE 1: dense gradient output (compat backward)
 // =============================================================================================
-#define HSK_DUP_MAX 8   // duplicate entries of one user the catch-up kernel lists for the owner (more: batch scan)
 
 template <int V, int NCH, bool FULL>
 __device__ __forceinline__ void hsk_user_grad(hsk_row<V, NCH>& acc, float& gbias_unused, int row, int b0, int c,
@@ -356,19 +444,6 @@ __global__ __launch_bounds__(256) void k_user_update(float* __restrict__ Uw, flo
 // have executed -- results are bit-identical to the dense sweep, HBM traffic is only the touched rows.
 // tab[t] = (ss_t, bc2s_t) for t in [1, tab_len]; for t > tab_len the entry tab_len applies (both saturated).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ hsk_adamw_consts hsk_consts_at(const hsk_adamw_consts& base, const float2* __restrict__ tab,
-                                                          int tab_len, int t) {
-  hsk_adamw_consts c = base;
-  const float2 e = tab[min(t, tab_len)];   // (step_size, bc2_sqrt or its reciprocal, see hsk_fused.hip)
-  c.step_size = e.x;
-#if HSK_ADAM_IEEE
-  c.bc2_sqrt = e.y;
-#else
-  c.rbc2_sqrt = e.y;
-#endif
-  return c;
-}
-
 // Zero-gradient replay of one user row by a whole 256-thread workgroup (thread t owns VV consecutive elements per
 // pass): the replay is a serial chain of `to - from` dependent updates per element, so a row is spread over as
 // many lanes as it has elements instead of being held by one wave.
@@ -462,7 +537,9 @@ __global__ __launch_bounds__(256) void k_item_catch_up(float* __restrict__ Iw, f
                                                        const int* __restrict__ touched,
                                                        const int* __restrict__ n_touched, int* __restrict__ last_step_i,
                                                        int D, int step, hsk_adamw_consts c,
-                                                       const float2* __restrict__ tab, int tab_len) {
+                                                       const float2* __restrict__ tab, int tab_len,
+                                                       const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0) {
+  if (desc) step = desc->step0 + rel + 1;   // graph replay (c's per-step fields are rebuilt per replayed step below)
   if ((int)blockIdx.x >= *n_touched) return;
   const int row = touched[blockIdx.x];
   const int done = last_step_i[row];
@@ -521,65 +598,229 @@ __device__ __forceinline__ void hsk_finish_block(const hsk_finish_args& f, const
   }
 }
 
-// Lazy mode, after the gradients: the owner applies step `step` to its (already current) row.  One extra workgroup
-// (blockIdx == ceil(B/4)) runs hsk_finish_block when `fin.loss_b` is set.
+// Lazy mode, after the gradients: the owner brings its row up to step-1 (pending zero-gradient steps; `tab` == NULL:
+// the row is current already) and applies step `step`.  One extra workgroup (bid == ceil(B/4)) runs hsk_finish_block
+// when `fin.loss_b` is set.  Body + argument block so that the item pass can carry these workgroups in its own launch.
+struct hsk_user_lazy_args {
+  float* Uw; float* mU; float* vU; float* Ub; float* mUb; float* vUb;
+  const float* dUb;       // [B, D] gradient rows by batch position
+  const int* u32;         // [B] table row of each batch position (-1: empty exchange slot)
+  int* owner; int* cnt; int* last_step;
+  int B, D, step;
+  hsk_adamw_consts c;
+  hsk_finish_args fin;
+  int* dupcnt; const int* duplist;
+  const float2* tab; int tab_len;   // tab == NULL: the table rows are current
+  const float* ucur; const float* mcur; const float* vcur;   // else: (p, m, v) of the rows that are behind, by batch
+                                                             // position, as the forward replayed them
+  int n_users;            // dense sweep (hsk_user_update_dense_body): rows of the table
+  const hsk_step_desc* desc; int rel;   // graph replay: step = desc->step0 + rel + 1, c from ctab
+  const float2* ctab; int ctab_len;
+};
+
+// step index and optimiser scalars of this launch: the immediate ones, or (graph replay) derived on the device
+__device__ __forceinline__ void hsk_resolve_step(const hsk_step_desc* desc, int rel, const float2* ctab, int ctab_len,
+                                                 int& step, hsk_adamw_consts& c) {
+  if (desc) {
+    step = desc->step0 + rel + 1;
+    c = hsk_consts_at(c, ctab, ctab_len, step);
+  }
+}
+
 template <int V, int NCH, bool FULL, bool GEN>
-__global__ __launch_bounds__(256) void k_user_update_lazy(float* __restrict__ Uw, float* __restrict__ mU,
-                                                          float* __restrict__ vU, float* __restrict__ Ub,
-                                                          float* __restrict__ mUb, float* __restrict__ vUb,
-                                                          const float* __restrict__ dUb, const int* __restrict__ u32,
-                                                          int* __restrict__ owner, int* __restrict__ cnt,
-                                                          int* __restrict__ last_step, int B, int D, int step,
-                                                          hsk_adamw_consts c,
-                                                          hsk_finish_args fin = hsk_finish_args{nullptr, 0, 0.0, nullptr,
-                                                                                                nullptr, nullptr, nullptr},
-                                                          int* __restrict__ dupcnt = nullptr,
-                                                          const int* __restrict__ duplist = nullptr) {
-  if (fin.loss_b && blockIdx.x == (unsigned)((B + 3) / 4)) {
-    hsk_finish_block(fin, c);
+__device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_args& a0, int bid) {
+  hsk_user_lazy_args a = a0;
+  hsk_resolve_step(a.desc, a.rel, a.ctab, a.ctab_len, a.step, a.c);
+  const int B = a.B, D = a.D, step = a.step;
+  if (a.fin.loss_b && bid == (B + 3) / 4) {
+    hsk_finish_block(a.fin, a.c);
     return;
   }
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
-  const int b = blockIdx.x * 4 + wave;
+  const int b = bid * 4 + wave;
   if (b >= B) return;
-  const int row = hsk_uniform_i(u32[b]);
+  const int row = hsk_uniform_i(a.u32[b]);
   if (row < 0) return;  // empty exchange slot (row-sharded mode)
   using Row = hsk_row<V, NCH>;
   // the row loads are issued together with the owner / count lookups (one memory latency instead of two); a
   // duplicate entry (not the owner) throws them away -- ~1 % of the entries at the BASELINE shapes
-  float* prow = Uw + (long long)row * D;
-  float* mrow = mU + (long long)row * D;
-  float* vrow = vU + (long long)row * D;
+  float* prow = a.Uw + (long long)row * D;
+  float* mrow = a.mU + (long long)row * D;
+  float* vrow = a.vU + (long long)row * D;
+  // tab != NULL: a row that still carries pending zero-gradient steps was replayed by the forward, which left the
+  // current (p, m, v) of the owner entry in ucur / mcur / vcur[b] (the table row itself is rewritten only here)
+  const int done = a.tab ? hsk_uniform_i(a.last_step[row]) : step - 1;
+  const bool behind = done < step - 1;
   Row p, m, v;
-  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
-  const int own = hsk_uniform_i(owner[row]);
-  const int n = hsk_uniform_i(cnt[row]);
+  hsk_row_load<V, NCH, FULL>(p, behind ? a.ucur + (long long)b * D : prow, lane, D);
+  hsk_row_load<V, NCH, FULL>(m, behind ? a.mcur + (long long)b * D : mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, behind ? a.vcur + (long long)b * D : vrow, lane, D);
+  const int own = hsk_uniform_i(a.owner[row]);
+  const int n = hsk_uniform_i(a.cnt[row]);
   if (own != b) return;
   Row g;
   float dummy = 0.f;
-  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, dUb, u32, B, D, lane, dupcnt, duplist);
+  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, a.dUb, a.u32, B, D, lane, a.dupcnt, a.duplist);
 #pragma unroll
   for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
-    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], c);
+    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], a.c);
   hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
   hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
   hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
   if (lane == 0) {
-    if (Ub) {
-      float pb = Ub[row], mb = mUb[row], vb = vUb[row];
-      hsk_adamw_update<GEN>(pb, mb, vb, 0.f, c);
-      Ub[row] = pb;
-      mUb[row] = mb;
-      vUb[row] = vb;
+    if (a.Ub) {
+      float pb = a.Ub[row], mb = a.mUb[row], vb = a.vUb[row];
+      for (int t = done + 1; t <= step - 1; ++t)
+        hsk_adamw_update<GEN>(pb, mb, vb, 0.f, hsk_consts_at(a.c, a.tab, a.tab_len, t));
+      hsk_adamw_update<GEN>(pb, mb, vb, 0.f, a.c);
+      a.Ub[row] = pb;
+      a.mUb[row] = mb;
+      a.vUb[row] = vb;
     }
-    last_step[row] = step;
+    a.last_step[row] = step;
     // last reader of the owner map this step; a duplicate entry that reads NONE afterwards just exits
-    owner[row] = HSK_OWNER_NONE;
-    cnt[row] = 0;
+    a.owner[row] = HSK_OWNER_NONE;
+    a.cnt[row] = 0;
+  }
+}
+
+template <int V, int NCH, bool FULL, bool GEN>
+__global__ __launch_bounds__(256) void k_user_update_lazy(hsk_user_lazy_args a) {
+  hsk_user_update_lazy_body<V, NCH, FULL, GEN>(a, (int)blockIdx.x);
+}
+
+// Dense mode (small user tables: the sweep is cheaper than replaying): AdamW on EVERY row of the table, the batch
+// rows with their gradient (owner map, duplicates by batch scan), all others with g = 0 -- torch.optim's own order of
+// operations.  One wave per table row; workgroup ceil(n_users/4) runs hsk_finish_block.
+template <int V, int NCH, bool FULL, bool GEN>
+__device__ __forceinline__ void hsk_user_update_dense_body(const hsk_user_lazy_args& a0, int bid) {
+  hsk_user_lazy_args a = a0;
+  hsk_resolve_step(a.desc, a.rel, a.ctab, a.ctab_len, a.step, a.c);
+  const int U = a.n_users, D = a.D;
+  if (a.fin.loss_b && bid == (U + 3) / 4) {
+    hsk_finish_block(a.fin, a.c);
+    return;
+  }
+  const int lane = hsk_lane();
+  const int row = bid * 4 + hsk_uniform_i(threadIdx.x >> 6);
+  if (row >= U) return;
+  using Row = hsk_row<V, NCH>;
+  float* prow = a.Uw + (long long)row * D;
+  float* mrow = a.mU + (long long)row * D;
+  float* vrow = a.vU + (long long)row * D;
+  Row p, m, v, g;
+  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  const int n = hsk_uniform_i(a.cnt[row]);
+  if (n > 0) {
+    float dummy = 0.f;
+    hsk_user_grad<V, NCH, FULL>(g, dummy, row, hsk_uniform_i(a.owner[row]), n, a.dUb, a.u32, a.B, D, lane);
+    if (lane == 0) {
+      a.owner[row] = HSK_OWNER_NONE;
+      a.cnt[row] = 0;
+    }
+  } else {
+    hsk_row_zero(g);
+  }
+#pragma unroll
+  for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], a.c);
+  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  if (a.Ub && lane == 0) {
+    // d loss / d user_bias is identically 0 under BPR (it cancels in s_pos - s_neg)
+    float pb = a.Ub[row], mb = a.mUb[row], vb = a.vUb[row];
+    hsk_adamw_update<GEN>(pb, mb, vb, 0.f, a.c);
+    a.Ub[row] = pb;
+    a.mUb[row] = mb;
+    a.vUb[row] = vb;
+  }
+}
+
+template <int V, int NCH, bool FULL, bool GEN>
+__global__ __launch_bounds__(256) void k_user_update_dense(hsk_user_lazy_args a) {
+  hsk_user_update_dense_body<V, NCH, FULL, GEN>(a, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Catch-up AHEAD of time.  The replay of a row's pending zero-gradient steps is pure VALU work (two transcendentals
+// per element and step); inside the forward it sits at the head of every wave's critical path.  The step knows its
+// NEXT batch (the prefetch hint), so workgroups riding in the item pass's launch -- memory-bound, VALU idle -- bring
+// the next batch's user rows up to the CURRENT step (inclusive: those users are not in the current batch, so the
+// current step is one more zero-gradient step for them) and the next forward finds them current.  A row that is in
+// the current batch too is skipped (`stamp`): its owner is rewriting it in this very launch.  Two entries of the next
+// batch naming the same user: the first to raise `claim[u]` to this step does the work.  Purely an optimisation: a row
+// nobody brought up to date is replayed by the forward as before; results are bit-identical either way.
+// ---------------------------------------------------------------------------------------------
+struct hsk_ahead_args {
+  const int32_t* coo_user;   // NULL: nothing to do
+  const int64_t* order;
+  long long start;           // next batch: interactions order[start .. start + n)
+  int n;
+  const int* stamp_cur;      // stamp of the batch being trained on (== step for its users)
+  int* claim;
+  float* Uw; float* mU; float* vU; float* Ub; float* mUb; float* vUb;
+  int* last_step;
+  int D, step;               // step: the step being taken
+  hsk_adamw_consts c;
+  const float2* tab; int tab_len;
+  const hsk_step_desc* desc; int rel;   // graph replay: next batch = desc batch rel + 1
+};
+
+// One WAVE per entry of the next batch (4 per workgroup): a wave slot is what these workgroups take from the item pass.
+template <int V, int NCH, bool FULL, bool GEN>
+__device__ __forceinline__ void hsk_user_ahead_body(const hsk_ahead_args& a, int bid) {
+  const int lane = hsk_lane();
+  const int b = bid * 4 + hsk_uniform_i(threadIdx.x >> 6);
+  if (b >= a.n) return;
+  int step = a.step;
+  long long start = a.start;
+  const int64_t* order = a.order;
+  if (a.desc) {
+    step = a.desc->step0 + a.rel + 1;
+    start = a.desc->start0 + (long long)(a.rel + 1) * a.n;
+    order = a.desc->order;
+  }
+  const long long pos = order ? (long long)order[start + b] : (start + b);
+  const int u = hsk_uniform_i(a.coo_user[pos]);
+  if (hsk_uniform_i(a.stamp_cur[u]) == step) return;   // in the current batch: being updated right now
+  const int done = hsk_uniform_i(a.last_step[u]);
+  if (done >= step) return;
+  int won = 0;
+  if (lane == 0) won = atomicMax(&a.claim[u], step) < step;
+  if (!hsk_uniform_i(won)) return;                     // another entry of the next batch names the same user
+  const int D = a.D;
+  float* prow = a.Uw + (long long)u * D;
+  float* mrow = a.mU + (long long)u * D;
+  float* vrow = a.vU + (long long)u * D;
+  hsk_row<V, NCH> p, m, v;
+  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  for (int t = done + 1; t <= step; ++t) {
+    const hsk_adamw_consts ct = hsk_consts_at(a.c, a.tab, a.tab_len, t);
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int q = 0; q < V; ++q) hsk_adamw_replay<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+  }
+  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  if (lane == 0) {
+    if (a.Ub) {
+      float pb = a.Ub[u], mb = a.mUb[u], vb = a.vUb[u];
+      for (int t = done + 1; t <= step; ++t) hsk_adamw_update<GEN>(pb, mb, vb, 0.f, hsk_consts_at(a.c, a.tab, a.tab_len, t));
+      a.Ub[u] = pb;
+      a.mUb[u] = mb;
+      a.vUb[u] = vb;
+    }
+    a.last_step[u] = step;
   }
 }
 

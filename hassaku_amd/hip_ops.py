@@ -198,6 +198,7 @@ def adamw_dense(p, g, m, v, lr, wd, step, beta1=ADAM_BETA1, beta2=ADAM_BETA2, ep
                'hsk_adamw_dense')
 
 
+LAZY_USERS_MIN_ELEMENTS = 4_000_000   # user tables above this many elements are updated lazily (BprMfFusedState)
 OPT_KINDS = {'adamw': 0, 'adam': 1, 'adagrad': 2}            # HSK_OPT_* (conf['optimizer'], train/trainer.py:48-53)
 ADAGRAD_EPS = 1e-10                                           # torch.optim.Adagrad default
 
@@ -284,8 +285,8 @@ class BprMfFusedState:
 
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=None, seed=0,
-                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users=True, overlap=True,
-                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto'):
+                 csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users='auto', overlap=True,
+                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto', graph_chunk=0):
         _lib.require_gpu()
         if optimizer not in OPT_KINDS:
             raise ValueError(f'Optimizer {optimizer} not yet implemented')
@@ -338,8 +339,14 @@ class BprMfFusedState:
         st.seed = seed & 0xFFFFFFFFFFFFFFFF
         st.workspace, st.workspace_bytes = _p(self.workspace), nbytes
         st.max_batch, st.max_cols = self.max_batch, self.max_cols
-        # exact lazy AdamW on user rows (bit-identical to the dense sweep after flush()); dense when False
+        # exact lazy AdamW on user rows (bit-identical to the dense sweep after flush()); dense when False.  'auto':
+        # a small table is swept densely inside the item pass's launch (24 B per element and step) -- cheaper than
+        # replaying ~U/B pending steps per touched row; a large one is updated lazily
+        if lazy_users == 'auto':
+            lazy_users = n_users * dim > LAZY_USERS_MIN_ELEMENTS
         st.lazy_users = 1 if lazy_users else 0
+        # steps_sampled() replays its steady-state loop as HIP graphs of this many steps (0: default 64, < 0: never)
+        st.graph_chunk = int(graph_chunk)
         st.timing_mask = 0
         if loss not in LOSS_KINDS:
             raise ValueError(f'unknown loss {loss!r}')
@@ -397,6 +404,10 @@ class BprMfFusedState:
         _lib.check(self.lib.hsk_bprmf_train_steps(ctypes.byref(self.st), _p(order), start, n_steps, batch, n_neg,
                                                   _stream()), 'hsk_bprmf_train_steps')
 
+    def graph_replays(self) -> int:
+        """Runs of steps_sampled() issued as replayed HIP graphs so far."""
+        return int(self.lib.hsk_bprmf_graph_replays(ctypes.byref(self.st)))
+
     def hint_next(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int):
         """Name the batch of the NEXT step_sampled call so that the step issued now prepares it on the side stream.
         No-op without overlap=True.  batch <= 0 clears a pending hint."""
@@ -416,6 +427,14 @@ class BprMfFusedState:
         _lib.check(self.lib.hsk_bprmf_last_batch(ctypes.byref(self.st), batch, n_cols, _p(u), _p(i), _stream()),
                    'hsk_bprmf_last_batch')
         return u, i
+
+    def last_sort(self, n_entries: int):
+        """(perm int32 [n_entries], offsets int32 [n_items + 1]): the item-major index of the last step's batch."""
+        perm = torch.empty(n_entries, dtype=torch.int32, device=self.device)
+        offs = torch.empty(self.params['item_emb'].shape[0] + 1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsk_bprmf_last_sort(ctypes.byref(self.st), n_entries, _p(perm), _p(offs), _stream()),
+                   'hsk_bprmf_last_sort')
+        return perm, offs
 
     STAGES = ('prep', 'scan', 'scatter', 'fwd', 'item', 'user', 'finish')
 

@@ -214,7 +214,9 @@ typedef struct hsk_bprmf_state {
      zero-gradient steps until it is next touched or flushed; bit-identical to the dense update).  For catalogues far
      larger than a batch touches; needs an even dim.  0 (default): every item row is updated every step */
   int32_t lazy_items;
-  int32_t reserved2;
+  /* hsk_bprmf_train_steps replays its steady-state loop as captured HIP graphs of this many steps (0: default 64,
+     < 0: never, eager launches only); per-step scalars are read from a device descriptor, results are bit-identical */
+  int32_t graph_chunk;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;
@@ -274,9 +276,14 @@ int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, int64_t start
 /* n_steps consecutive hsk_bprmf_train_step_sampled calls on the batches order[start + s*batch .. +batch), s < n_steps,
  * each hinting the next one to the prefetch (when st->aux is set): the inner loop of an epoch (train/trainer.py:128-148)
  * issued from C.  At small batches the step is bound by the host's launch rate (ten HIP calls of 3-4 us each plus the
- * interpreter), not by the GPU; this removes the interpreter's share. */
+ * interpreter), not by the GPU: with st->aux set (and an even dim, no lazy_items, no stage timing) runs of consecutive
+ * steps are captured once as a HIP graph and REPLAYED (st->graph_chunk steps per graph), the per-step scalars coming
+ * from a device-resident descriptor; same kernels, same order, bit-identical results. */
 int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t n_steps, int64_t batch,
                           int64_t n_neg, hsk_stream_t stream);
+
+/* number of runs hsk_bprmf_train_steps has issued as replayed graphs so far (0 when every step was launched eagerly) */
+int64_t hsk_bprmf_graph_replays(const hsk_bprmf_state* st);
 
 /* Bring lazily-updated user / item rows up to st->step (no-op with dense updates); also drops a pending hint and a
  * prefetched batch that was never trained on (a flush ends a run of steps). */
@@ -285,6 +292,13 @@ int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
 /* Copy of the device batch the last *_sampled step used (debug / parity): u [batch], items [batch,n_cols] */
 int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols,
                          int64_t* u_out, int64_t* i_out, hsk_stream_t stream);
+
+/* Copy of the item-major index the last step built from its batch (debug / parity): perm int32[n_entries] = the
+ * batch entries e = b*n_cols + k grouped by item, ascending e inside an item; offsets int32[n_items + 1] = where each
+ * item's entries start in perm.  Three kernels build it depending on the shape (csrc/hsk_sort.h); all must return
+ * exactly this. */
+int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries, int32_t* perm_out, int32_t* offsets_out,
+                        hsk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU fused step: one process per GPU; replaces nn.DataParallel (train/trainer.py:38-41).

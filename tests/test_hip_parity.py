@@ -379,34 +379,84 @@ def test_prefetched_batches_change_nothing(ops):
         assert np.array_equal(base[k], pref[k]), k
 
 
-def test_multi_step_call_equals_single_steps(ops):
-    """hsk_bprmf_train_steps (the epoch's inner loop issued from C) == the same steps issued one by one."""
+@pytest.mark.parametrize('shape', [
+    # (n_users, n_items, D, B, N, lazy_users, steps in the first / second chunked call)
+    (150, 260, 96, 64, 70, True, 40, 30),        # below the graph chunk: eager launches from C
+    (300, 400, 402, 128, 50, False, 150, 75),    # BASELINE configs[1] row / batch shape, dense user sweep: replayed graphs
+    (300, 400, 402, 128, 50, True, 150, 75),     # the same with the lazy user AdamW (flush after every replayed run)
+    (200, 500, 64, 128, 1, False, 200, 25),      # BASELINE configs[0] row / batch shape (one negative: 256 entries)
+    (900, 700, 128, 2048, 10, True, 70, 66),     # a batch large enough for the late fork + four-kernel sort in the graph
+])
+def test_multi_step_call_equals_single_steps(ops, shape):
+    """hsk_bprmf_train_steps (the epoch's inner loop issued from C; runs of 64 steps as replayed HIP graphs whose
+    kernels read the batch offset / step index from a device descriptor) == the same steps issued one by one from the
+    host, bit for bit: parameters, moments and the loss sum."""
+    n_users, n_items, D, B, N, lazy, n1, n2 = shape
     rng = np.random.RandomState(4)
-    n_users, n_items, D, B, N = 150, 260, 96, 64, 70
     pairs = np.argwhere(rng.rand(n_users, n_items) < 0.15)
     pairs = pairs[rng.permutation(len(pairs))]
     ptr, idx = csr_from_pairs(pairs, n_users)
     P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
          'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
          'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
-    order = torch.from_numpy(np.random.RandomState(6).permutation(len(pairs))).cuda()
+    n_pos = len(pairs)
+    reps = -(-(n1 + n2) * B // n_pos)
+    order = torch.from_numpy(np.concatenate([np.random.RandomState(6 + r).permutation(n_pos) for r in range(reps)])).cuda()
     res = []
     for chunked in (False, True):
         st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
-                             coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+                             coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32),
+                             lazy_users=lazy)
+        st.st.nnz = order.numel()      # the run walks `order`, which repeats the interactions
         if chunked:
-            st.steps_sampled(order, 0, 40, B, N)
-            st.steps_sampled(order, 40 * B, 30, B, N)
+            st.steps_sampled(order, 0, n1, B, N)
+            st.step_sampled(order, n1 * B, B, N)             # an eager step between two replayed runs
+            st.steps_sampled(order, (n1 + 1) * B, n2 - 1, B, N)
         else:
-            for s in range(70):
+            for s in range(n1 + n2):
                 st.step_sampled(order, s * B, B, N)
         st.flush()
         st.check_status()
-        assert st.step_count == 70
-        res.append(({k: v.cpu().numpy().copy() for k, v in t.items()}, st.pop_loss_sum()))
-    assert res[0][1] == res[1][1]
+        assert st.step_count == n1 + n2
+        # the chunked run really went through the graphs: every full run of 64 steps inside the two calls
+        assert st.graph_replays() == ((n1 // 64 + (n2 - 1) // 64) if chunked else 0)
+        mom = {'m_' + k: v.cpu().numpy().copy() for k, v in st.m.items() if v is not None}
+        mom.update({'v_' + k: v.cpu().numpy().copy() for k, v in st.v.items() if v is not None})
+        res.append(({k: v.cpu().numpy().copy() for k, v in t.items()}, mom, st.pop_loss_sum()))
+    assert res[0][2] == res[1][2]
     for k in res[0][0]:
         assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    for k in res[0][1]:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize('shape', [
+    # (n_users, n_items, D, B, K): which of the three item sorts the step picks
+    (300, 3706, 32, 128, 51),     # k_sort_lds: <= 8192 entries, <= 4 per item on average (BASELINE configs[1] shape)
+    (300, 1682, 32, 128, 2),      # k_sort_lds, 256 entries (BASELINE configs[0] shape)
+    (300, 40, 32, 100, 12),       # k_sort_lds is not eligible (30 entries per item): block radix sort
+    (300, 2000, 32, 64, 101),     # k_sort_lds with popular items: lists far longer than 8 entries (wave rank pass)
+    (300, 5000, 32, 1024, 33),    # > 8192 entries: the four-kernel two-level sort
+])
+def test_item_sort_is_the_stable_sort_by_item(ops, shape):
+    """perm / offsets of the step's batch == numpy's stable argsort of the item ids, whichever kernel built them."""
+    n_users, n_items, D, B, K = shape
+    rng = np.random.RandomState(11)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32)}
+    st, _ = _fused_state(ops, P, 1e-3, 0.0, B, K)
+    u = rng.randint(0, n_users, size=B).astype(np.int64)
+    i = rng.randint(0, n_items, size=(B, K)).astype(np.int64)
+    if shape[1] == 2000:                       # a few very popular items
+        i[rng.rand(B, K) < 0.3] = rng.randint(0, 5, size=int((rng.rand(B, K) < 0.3).sum())) if False else 3
+        i[:, 0] = 7
+    st.step(dev(u), dev(i))
+    perm, offs = (x.cpu().numpy() for x in st.last_sort(B * K))
+    flat = i.reshape(-1)
+    want = np.argsort(flat, kind='stable')
+    assert np.array_equal(perm, want)
+    assert np.array_equal(offs, np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=n_items))]))
+    st.check_status()
 
 
 def test_wrong_hints_are_discarded(ops):
