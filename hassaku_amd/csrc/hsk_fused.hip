@@ -435,7 +435,10 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
   static const int ipw = getenv("HSK_ITEM_IPW") ? atoi(getenv("HSK_ITEM_IPW")) : 1;
   const int vs = force_vs == 2 ? 2 : (D % 4 == 0) ? 4 : 2;
   const int n_sl = (int)hsk_ceil_div(D, 64 * vs);
-  const int n_slices_pad = (n_sl < 8 && 8 % n_sl == 0) ? n_sl : (int)hsk_align_up(n_sl, 8);
+  // merged launch at a small batch: whole-row item workgroups (n_slices_pad = 0 tells the kernel), see hsk_item_row_body
+  static const int rows_on = getenv("HSK_ITEM_ROWS") ? atoi(getenv("HSK_ITEM_ROWS")) : 1;
+  const bool whole_rows = APPLY && ua && rows_on && n_entries <= 64 * 1024;
+  const int n_slices_pad = whole_rows ? 0 : (n_sl < 8 && 8 % n_sl == 0) ? n_sl : (int)hsk_align_up(n_sl, 8);
   const bool lazy = APPLY && st->lazy_items;
   // lazy item AdamW: only the items with entries (the sort's `touched` list; at most one per entry)
   const int64_t n_list = lazy ? std::min<int64_t>(I, n_entries) : I;
@@ -445,7 +448,7 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
                             gI_out, gIb_out, w.touched, w.n_touched, w.last_step_i, (int)st->step,
                             ua ? ua->desc : nullptr, ua ? ua->rel : 0, w.adam_tab, HSK_ADAM_TAB_LEN};
   const bool gen = APPLY && st->opt_kind != HSK_OPT_ADAMW;   // APPLY == false never calls the update
-  const unsigned nblk = groups * n_slices_pad;
+  const unsigned nblk = groups * (whole_rows ? 1 : n_slices_pad);
   if (APPLY && ua) {
     const int dense = ua->n_users > 0;
     const int nub = (int)hsk_align_up(hsk_ceil_div(dense ? ua->n_users : ua->B, 4) + 1, 8);
@@ -704,22 +707,23 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
                           inv_bn, (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b, (const int*)nullptr, lz)
     // small batches: a workgroup per positive (hsk_fwd_small.h); the one-wave kernel would leave most SIMDs idle
     // and walk each positive's rows as a chain of memory latencies
-#define HSK_LAUNCH_FWD_WG(LK)                                                                                       \
+#define HSK_LAUNCH_FWD_WG(LK, NW)                                                                                   \
   if (capturing)                                                                                                    \
-    hipLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK>), dim3((unsigned)B), dim3(256),                           \
-                       (unsigned)(4 * (size_t)D * sizeof(float)), stream, (const float*)st->user_emb,               \
+    hipLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK, NW>), dim3((unsigned)B), dim3(64 * NW),                    \
+                       (unsigned)(NW * (size_t)D * sizeof(float)), stream, (const float*)st->user_emb,              \
                        (const float*)st->item_emb, (const float*)st->item_bias, (const int*)w.u32,                  \
                        (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b, lz);                   \
   else                                                                                                              \
-    hipExtLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK>), dim3((unsigned)B), dim3(256),                        \
-                          (unsigned)(4 * (size_t)D * sizeof(float)), stream, fwd_beg, fwd_end, 0,                    \
+    hipExtLaunchKernelGGL((k_fwd_ugrad_wg<V, NCH, FULL, R, LK, NW>), dim3((unsigned)B), dim3(64 * NW),                 \
+                          (unsigned)(NW * (size_t)D * sizeof(float)), stream, fwd_beg, fwd_end, 0,                   \
                           (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,      \
                           (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b, lz)
     const bool wg_fwd = B <= 1024 && st->loss_kind != HSK_LOSS_SSM && K >= 9;
+    const bool wg8 = wg_fwd && K >= 33 && B <= 256;   // few, wide positives: 8 waves each
     if (wg_fwd && st->loss_kind == HSK_LOSS_BCE) {
-      HSK_LAUNCH_FWD_WG(HSK_LOSS_BCE);
+      if (wg8) { HSK_LAUNCH_FWD_WG(HSK_LOSS_BCE, 8); } else { HSK_LAUNCH_FWD_WG(HSK_LOSS_BCE, 4); }
     } else if (wg_fwd) {
-      HSK_LAUNCH_FWD_WG(HSK_LOSS_BPR);
+      if (wg8) { HSK_LAUNCH_FWD_WG(HSK_LOSS_BPR, 8); } else { HSK_LAUNCH_FWD_WG(HSK_LOSS_BPR, 4); }
     } else if (st->loss_kind == HSK_LOSS_BCE) {
       HSK_LAUNCH_FWD(HSK_LOSS_BCE);
     } else if (st->loss_kind == HSK_LOSS_SSM) {

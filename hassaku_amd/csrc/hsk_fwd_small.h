@@ -11,16 +11,18 @@
 #pragma once
 #include "hsk_rows.h"
 
-template <int V, int NCH, bool FULL, int R, int LOSS>
-__global__ __launch_bounds__(256) void k_fwd_ugrad_wg(const float* __restrict__ Uw, const float* __restrict__ Iw,
+// NW waves per workgroup (4 or 8): with 8, a positive's 50 negatives are 6-7 rows per wave -- all in flight at once,
+// i.e. one round of memory latency instead of two.
+template <int V, int NCH, bool FULL, int R, int LOSS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_fwd_ugrad_wg(const float* __restrict__ Uw, const float* __restrict__ Iw,
                                                       const float* __restrict__ Ib, const int* __restrict__ u32,
                                                       const int* __restrict__ it32, int B, int K, int D,
                                                       float inv_norm, float* __restrict__ g_s,
                                                       float* __restrict__ dUb, double* __restrict__ loss_b,
                                                       hsk_lazy_user_args lz = hsk_lazy_user_args{}) {
-  extern __shared__ float lds_rows[];   // [4][D]: partial gradient rows of waves 1..3 (slot 0 unused)
-  __shared__ float sh_gsum[4];
-  __shared__ double sh_loss[4];
+  extern __shared__ float lds_rows[];   // [NW][D]: partial gradient rows of waves 1.. (slot 0 unused)
+  __shared__ float sh_gsum[NW];
+  __shared__ double sh_loss[NW];
   const int lane = hsk_lane();
   const int sub = hsk_uniform_i(threadIdx.x >> 6);
   const int b = blockIdx.x;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad_wg(const float* __restrict__ 
   hsk_row_zero(acc);
   const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
 
-  const int per = (K - 1 + 3) / 4;                 // columns per wave
+  const int per = (K - 1 + NW - 1) / NW;           // columns per wave
   const int k_lo = 1 + sub * per, k_hi = min(K, k_lo + per);
   float gsum = 0.f;
   double lsum = 0.0;
@@ -102,15 +104,21 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad_wg(const float* __restrict__ 
   __syncthreads();
   if (sub != 0) return;
 #pragma unroll
-  for (int w = 1; w < 4; ++w) {
+  for (int w = 1; w < NW; ++w) {
     Row t;
     hsk_row_load<V, NCH, FULL>(t, lds_rows + (long long)w * D, lane, D);
     hsk_row_add(acc, t);
   }
   float g0;
-  double ltot = ((sh_loss[0] + sh_loss[1]) + sh_loss[2]) + sh_loss[3];
+  double ltot = sh_loss[0];
+  float gtot = sh_gsum[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {   // wave order: deterministic
+    ltot += sh_loss[w];
+    gtot += sh_gsum[w];
+  }
   if (LOSS == HSK_LOSS_BPR) {
-    g0 = -(((sh_gsum[0] + sh_gsum[1]) + sh_gsum[2]) + sh_gsum[3]);   // d loss / d s_pos
+    g0 = -gtot;   // d loss / d s_pos
   } else {
     g0 = -inv_norm / (1.f + expf(s0));   // (sigma(s_0) - 1)/(B*K)
     ltot += (double)hsk_softplus(-s0);

@@ -164,6 +164,73 @@ __device__ __forceinline__ void hsk_item_sliced_body(const hsk_item_args& a, int
   }
 }
 
+// Whole rows, one wave per item -- what a SMALL batch wants: with a few thousand entries everything is cache-resident
+// and the pass is a chain of latencies per wave (offsets -> perm -> g_s -> rows), so the fewer waves the better; the
+// D-slices above multiply them by the number of slices for an L2 affinity that only matters when the chip is full.
+// LAZY: only the items in `touched`.
+template <int V, int NCH, bool FULL, bool GEN, bool LAZY>
+__device__ __forceinline__ void hsk_item_row_body(const hsk_item_args& a, int bid) {
+  const int lane = hsk_lane();
+  const int idx = bid * 4 + hsk_uniform_i(threadIdx.x >> 6);
+  const int n_list = LAZY ? hsk_uniform_i(*a.n_touched) : a.n_items;
+  if (idx >= n_list) return;
+  hsk_adamw_consts c = a.c;
+  int step = a.step;
+  hsk_resolve_step(a.desc, a.rel, a.ctab, a.ctab_len, step, c);
+  const int i = LAZY ? hsk_uniform_i(a.touched[idx]) : idx;
+  const int D = a.D, K = a.K;
+  using Row = hsk_row<V, NCH>;
+  const int beg = hsk_uniform_i(a.offsets[i]);
+  const int end = hsk_uniform_i(a.offsets[i + 1]);
+  float* prow = a.Iw + (long long)i * D;
+  float* mrow = a.mI + (long long)i * D;
+  float* vrow = a.vI + (long long)i * D;
+  Row p, m, v, acc;
+  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);   // AdamW operands early: their latency hides under the gather
+  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  hsk_row_zero(acc);
+  float gb_lane = 0.f;
+  for (int c0 = beg; c0 < end; c0 += 64) {
+    const int nr = min(64, end - c0);
+    int myu = 0;
+    float myg = 0.f;
+    if (lane < nr) {
+      const int e = a.perm[c0 + lane];
+      myg = a.g_s[e];
+      myu = a.u32 ? a.u32[e / K] : e / K;
+    }
+    gb_lane += myg;
+    for (int j = 0; j < nr; j += 4) {
+      Row buf[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (j + r < nr) hsk_row_load<V, NCH, FULL>(buf[r], a.Uw + (long long)hsk_readlane_i(myu, min(j + r, 63)) * D, lane, D);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (j + r < nr) hsk_row_axpy(acc, hsk_readlane_f(myg, j + r), buf[r]);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], acc.c[cc].v[q], c);
+  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  if (a.Ib) {
+    const float gbias = hsk_wave_sum(gb_lane);
+    if (lane == 0) {
+      float pb = a.Ib[i], mb = a.mIb[i], vb = a.vIb[i];
+      hsk_adamw_update<GEN>(pb, mb, vb, gbias, c);
+      a.Ib[i] = pb;
+      a.mIb[i] = mb;
+      a.vIb[i] = vb;
+    }
+  }
+  if (LAZY && lane == 0) a.last_step_i[i] = step;
+}
+
 template <bool APPLY, int VS, bool GEN, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
   hsk_item_sliced_body<APPLY, VS, GEN, LAZY>(a, (int)blockIdx.x);
@@ -204,5 +271,8 @@ __global__ __launch_bounds__(256) void k_item_user(hsk_item_args ia, hsk_user_la
       item_oct = n_ahead_oct * stride + (q - full);
     }
   }
-  hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, item_oct * 8 + r);
+  if (ia.n_slices_pad == 0)   // small batches: whole rows (see hsk_item_row_body)
+    hsk_item_row_body<V, NCH, FULL, GEN, LAZYI>(ia, item_oct * 8 + r);
+  else
+    hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, item_oct * 8 + r);
 }

@@ -282,7 +282,7 @@ class ShardedBprMf:
         st.max_batch, st.max_cols = max_batch, max_cols
         st.lazy_users = 1
         if lazy_items == 'auto':   # worth it when most of the shard's rows are outside every batch
-            lazy_items = D % 2 == 0 and I_loc >= 2 * cap
+            lazy_items = D % 2 == 0 and I_loc >= 2 * cap and I_loc * D > hip_ops.LAZY_USERS_MIN_ELEMENTS
         st.lazy_items = 1 if lazy_items else 0
         st.timing_mask, st.timing, st.aux, st.timing_every, st.timing_now = 0, None, None, 1, 0
         st.loss_kind, st.ssm_log_adjust = hip_ops.LOSS_KINDS[loss], float(log_adjust)
