@@ -262,12 +262,14 @@ class _EvalData:
         return self._arr
 
 
-def run_eval(shape, device, comm=None, chunk=2048, repeat=3):
+def run_eval(shape, device, comm=None, chunk=None, repeat=3):
     """Full-catalogue evaluation (scores U x I^T, exclusion mask, top-100, precision/recall/ndcg at 100/50/10/5).
     comm None: one GPU.  Otherwise ITEM-SHARDED over the ranks on physically sliced tables (dist.evaluate_item_sharded)."""
     from hassaku_amd import hip_ops as ops
     from hassaku_amd.eval.eval import FullEvaluator
     U, I, D, npos = EVAL_SHAPES[shape]
+    if chunk is None:     # wide catalogue: top-k inside the GEMM, big chunks; narrow: materialised scores
+        chunk = 16384 if I >= ops.FUSED_TOPK_MIN_ITEMS else 8192
     torch.manual_seed(0)
     user_emb = torch.randn(U, D, device=device) * 0.05
     item_emb = torch.randn(I, D, device=device) * 0.05
@@ -278,14 +280,13 @@ def run_eval(shape, device, comm=None, chunk=2048, repeat=3):
     world = 1 if comm is None else comm.world
     if comm is None:
         arr = ds.device_arrays(device)
-        scores = torch.empty((chunk, I), dtype=torch.float32, device=device)
 
         def one_pass():
             acc = torch.zeros((len(ks), 3), dtype=torch.float64, device=device)
             for lo in range(0, U, chunk):
                 u = torch.arange(lo, min(lo + chunk, U), device=device)
                 _, ids, _ = ops.mf_eval_topk(user_emb, item_emb, item_bias, None, None, u, ks[0], arr['excl_indptr'],
-                                             arr['excl_indices'], scores_ws=scores)
+                                             arr['excl_indices'])
                 acc += ops.rank_metrics(ids, u, arr['label_indptr'], arr['label_indices'], ks).double().sum(0)
             return {f'ndcg@{k}': float(acc[t, 2] / U) for t, k in enumerate(ks)}
     else:
@@ -293,7 +294,7 @@ def run_eval(shape, device, comm=None, chunk=2048, repeat=3):
         shards = TableShards.cut(comm, user_emb, item_emb, item_bias)
         del user_emb, item_emb, item_bias
 
-        chunk = min(chunk * world, U)     # a rank scores chunk x I/world: the per-rank GEMM stays the single-GPU size
+        chunk = min(chunk, U)
 
         def one_pass():
             return evaluate_item_sharded(comm, shards, ds, ev, chunk=chunk)

@@ -107,6 +107,10 @@ SIGNATURES = {
     'hsk_mf_eval_topk': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,
                                                                  c_void_p, c_void_p, c_int64,
                                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hsk_mf_eval_fused_ws_bytes': (c_int64, [c_int64] * 3),
+    'hsk_mf_eval_topk_fused': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,
+                                                                       c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     'hsk_topk_dense': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'hsk_topk_merge': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'hsk_rank_metrics': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

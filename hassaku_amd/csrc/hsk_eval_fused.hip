@@ -1,0 +1,505 @@
+// hsk_eval_fused.hip -- full-catalogue scoring with the top-k selection INSIDE the score GEMM: the [rows, items] score
+// matrix (1 GB per 2048 users at 131 072 items) is never written to memory.
+//
+// Reference semantics: eval/eval.py:237-253 (scores = U_batch x I^T + biases, -inf on the excluded positives) followed
+// by eval/eval.py:63 (logits.topk(k)).  Same arithmetic as k_score_gemm (hsk_eval.hip): exact-fp32 MFMA, biases added in
+// the reference's order, order of the result = (score descending, item id ascending).
+//
+// Work split: grid = (S item splits, row blocks of 128 users).  A workgroup walks the 128-column tiles of its split;
+// the 128 x 128 scores of a tile exist only in the MFMA accumulators.  Per row it keeps
+//     thr   its current k-th best score (-inf while it holds fewer than k)
+//     cand  up to HSK_SEL_CAP candidates (key << 32 | ~item id) in a global scratch slab, cnt of them
+// and the epilogue appends the tile's scores that reach thr.  After the first tiles a random score reaches thr with
+// probability ~k / (columns seen), so appends are rare: ~k ln(n / k) per row in total.  Whenever a row may overflow
+// during the next tile (cnt > CAP - 128), one wave sorts its candidates (bitonic, in LDS), keeps the best k and raises
+// thr.  At the end every row is compacted once more and its k best go out, sorted; hsk_topk_merge's kernel joins the S
+// lists of a row.  Excluded (user, item) pairs become -inf exactly as in the reference (they can still appear in the
+// top k of a user with fewer than k admissible items, lowest item id first).
+#include "hsk_common.h"
+
+#include <algorithm>
+
+typedef float hsk_f32x16 __attribute__((ext_vector_type(16)));
+
+#define FG_BM 128
+#define FG_BN 128
+#define FG_BK 32
+#define FG_LDS_STRIDE (FG_BK + 4)
+#ifndef HSK_SEL_CAP
+#define HSK_SEL_CAP 512            // candidates a row can hold between two compactions
+#endif
+#define HSK_SEL_KMAX 128           // k supported by the fused path
+#ifndef HSK_SEL_TRIG
+#define HSK_SEL_TRIG (HSK_SEL_CAP - FG_BN)   // a row is compacted when it holds more than this (<= CAP - 128)
+#endif
+
+__device__ __forceinline__ uint32_t fg_f2key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // ascending float order == ascending key order
+}
+__device__ __forceinline__ float fg_key2f(uint32_t k) {
+  const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(b);
+}
+
+// one wave sorts n <= HSK_SEL_CAP composite keys of `s` (LDS, padded with 0 up to npad, a power of two) descending
+__device__ __forceinline__ void fg_wave_bitonic_desc(unsigned long long* s, int npad, int lane) {
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order
+      for (int t = lane; t < (npad >> 1); t += 64) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = s[lo], b = s[hi];
+        if ((a < b) == desc) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__ Uw, const float* __restrict__ Iw,
+                                                    const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                    const float* __restrict__ gb, int n_users, int D,
+                                                    const int64_t* __restrict__ u_idx, int n_rows,
+                                                    long long item_begin, int item_count, int tiles_per_split,
+                                                    const int64_t* __restrict__ excl_indptr,
+                                                    const int32_t* __restrict__ excl_indices, int k, int n_splits,
+                                                    unsigned long long* __restrict__ cand_ws,
+                                                    float* __restrict__ part_vals, int32_t* __restrict__ part_idx,
+                                                    int32_t* status) {
+  __shared__ __attribute__((aligned(16))) float As[FG_BM * FG_LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Bs[FG_BN * FG_LDS_STRIDE];
+  __shared__ unsigned long long srt[4][HSK_SEL_KMAX];   // per-wave scratch of the final sort (k <= 128 keys)
+  __shared__ unsigned int hist[4][256];                 // per-wave digit histogram of the selection
+  __shared__ int urow[FG_BM];
+  __shared__ float ubias[FG_BM];
+  __shared__ float thr[FG_BM];      // current k-th best score of the row (-inf while it holds fewer than k)
+  __shared__ int cnt[FG_BM];
+  __shared__ uint32_t emask[FG_BM][4];      // exclusion bits of the current tile, one row of 128 bits per user
+  __shared__ long long eptr[FG_BM], eend[FG_BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // Workgroup -> (row block, split): consecutive workgroup ids go round the 8 XCDs, so id % 8 picks the row block
+  // inside a group of 8 and the next 8 ids the next split: one XCD then runs all the splits of only a few row blocks at
+  // a time -- their user rows (256 KB per row block, re-read for every tile) stay in its 4 MB L2, and an item tile is
+  // shared by the row blocks that walk the same split side by side.
+  const int n_row_blocks = (n_rows + FG_BM - 1) / FG_BM;
+  const int per_group = 8 * n_splits;
+  const int grp = blockIdx.x / per_group, rem = blockIdx.x - grp * per_group;
+  const int split = rem >> 3;
+  const int rb = grp * 8 + (rem & 7);
+  if (rb >= n_row_blocks) return;
+  const int m0 = rb * FG_BM;
+  const int n_tiles = (item_count + FG_BN - 1) / FG_BN;
+  const int t_lo = split * tiles_per_split, t_hi = min(n_tiles, t_lo + tiles_per_split);
+  unsigned long long* __restrict__ cand =
+      cand_ws + ((long long)rb * n_splits + split) * ((long long)FG_BM * HSK_SEL_CAP);
+
+  if (tid < FG_BM) {
+    const int r = m0 + tid;
+    int u = 0;
+    if (r < n_rows) {
+      long long uu = u_idx[r];
+      if (uu < 0 || uu >= n_users) {
+        if (status) atomicOr(status, HSK_STATUS_BAD_INDEX);
+        uu = 0;
+      }
+      u = (int)uu;
+    }
+    urow[tid] = u;
+    ubias[tid] = Ub ? Ub[u] : 0.f;
+    thr[tid] = -INFINITY;
+    cnt[tid] = 0;
+    long long lo = 0, hi = 0;
+    if (excl_indptr && r < n_rows) {
+      lo = excl_indptr[u];
+      hi = excl_indptr[u + 1];
+      // first excluded item at or beyond this split's first column (the row is sorted)
+      const long long first_col = item_begin + (long long)t_lo * FG_BN;
+      long long l = lo, h = hi;
+      while (l < h) {
+        const long long mid = (l + h) >> 1;
+        if (excl_indices[mid] < first_col)
+          l = mid + 1;
+        else
+          h = mid;
+      }
+      lo = l;
+    }
+    eptr[tid] = lo;
+    eend[tid] = hi;
+  }
+  __syncthreads();
+  // threads 0..127 walk "their" user's exclusion row; the next excluded item sits in a register, so a tile without
+  // excluded items (the usual case) costs no memory access
+  long long e_p = 0, e_end = 0, e_next = 0x7fffffffffffffffll;
+  if (tid < FG_BM) {
+    e_p = eptr[tid];
+    e_end = eend[tid];
+    if (e_p < e_end) e_next = excl_indices[e_p];
+  }
+
+  const int srow = tid >> 3;
+  const int scol = (tid & 7) * 4;
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+  const float gbv = gb ? gb[0] : 0.f;
+
+  // One wave, one row with n > k candidates: keep the best k (unsorted) and raise thr to the k-th best's key.
+  // The k-th largest composite key is found by an MSB-first radix SELECT (8 passes of 8 bits over <= CAP keys held in
+  // registers, digit histogram in LDS) -- ~10x cheaper than sorting the list, and nothing here needs an order: only
+  // the final lists are sorted.  Composite keys are unique (they end in the item id), so exactly k keys are >= it.
+  constexpr int KPL = HSK_SEL_CAP / 64;   // keys per lane
+  auto compact_row = [&](int rloc) {
+    const int n = cnt[rloc];
+    if (n <= k) return;
+    unsigned long long kv[KPL];
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+      const int j = lane + 64 * m;
+      kv[m] = (j < n) ? cand[(long long)rloc * HSK_SEL_CAP + j] : 0ull;
+    }
+    unsigned int* h = hist[wave];
+    unsigned long long prefix = 0ull, pmask = 0ull;
+    int need = k;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[lane * 4 + q] = 0u;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int m = 0; m < KPL; ++m)
+        if (kv[m] != 0ull && (kv[m] & pmask) == prefix) atomicAdd(&h[(unsigned)(kv[m] >> shift) & 255u], 1u);
+      __builtin_amdgcn_wave_barrier();
+      // lane l owns digits 4l .. 4l+3; keys with a higher digit than d: sum over digits > d
+      const unsigned c0 = h[lane * 4], c1 = h[lane * 4 + 1], c2 = h[lane * 4 + 2], c3 = h[lane * 4 + 3];
+      const int mine = (int)(c0 + c1 + c2 + c3);
+      int above = mine;   // inclusive suffix sum over lanes >= this one
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_down(above, off, 64);
+        if (lane + off < 64) above += t;
+      }
+      above -= mine;      // keys in digits owned by higher lanes
+      // the digit that holds the need-th largest key: the unique (lane, q) with above_d < need <= above_d + count_d
+      int found_digit = -1, found_need = 0;
+      {
+        int a3 = above, a2 = above + (int)c3, a1 = a2 + (int)c2, a0 = a1 + (int)c1;
+        if (a3 < need && need <= a3 + (int)c3) { found_digit = lane * 4 + 3; found_need = need - a3; }
+        else if (a2 < need && need <= a2 + (int)c2) { found_digit = lane * 4 + 2; found_need = need - a2; }
+        else if (a1 < need && need <= a1 + (int)c1) { found_digit = lane * 4 + 1; found_need = need - a1; }
+        else if (a0 < need && need <= a0 + (int)c0) { found_digit = lane * 4; found_need = need - a0; }
+      }
+      const unsigned long long who = __ballot(found_digit >= 0);
+      const int src = __builtin_ctzll(who);
+      const int digit = __shfl(found_digit, src, 64);
+      need = __shfl(found_need, src, 64);
+      prefix |= (unsigned long long)digit << shift;
+      pmask |= 0xffull << shift;
+    }
+    // prefix == the k-th largest composite key
+    int base = 0;
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+      const bool keep = kv[m] >= prefix && kv[m] != 0ull;
+      const unsigned long long bm = __ballot(keep);
+      if (keep) cand[(long long)rloc * HSK_SEL_CAP + base + __popcll(bm & ((1ull << lane) - 1ull))] = kv[m];
+      base += __popcll(bm);
+    }
+    if (lane == 0) {
+      cnt[rloc] = k;
+      thr[rloc] = fg_key2f((uint32_t)(prefix >> 32));
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // final: one wave, one row: its <= k survivors sorted (key descending, item id ascending) in LDS
+  auto sort_row = [&](int rloc, int keep) {
+    unsigned long long* sr = srt[wave];
+    for (int j = lane; j < HSK_SEL_KMAX; j += 64) sr[j] = (j < keep) ? cand[(long long)rloc * HSK_SEL_CAP + j] : 0ull;
+    fg_wave_bitonic_desc(sr, HSK_SEL_KMAX, lane);
+  };
+
+  float4 ra[4], rbv[4];   // register staging of the next k-tile (A: user rows, B: item rows)
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    const int n0 = tile * FG_BN;
+    // exclusion bits of this tile: the user's sorted CSR row is consumed as the tiles advance
+    if (tid < FG_BM) {
+      uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      const long long col_lo = item_begin + n0, col_hi = col_lo + FG_BN;
+      while (e_next < col_hi) {
+        const int c = (int)(e_next - col_lo);
+        if (c >= 0) {
+          const uint32_t bit = 1u << (c & 31);
+          if (c < 32) b0 |= bit; else if (c < 64) b1 |= bit; else if (c < 96) b2 |= bit; else b3 |= bit;
+        }
+        ++e_p;
+        e_next = (e_p < e_end) ? (long long)excl_indices[e_p] : 0x7fffffffffffffffll;
+      }
+      emask[tid][0] = b0;
+      emask[tid][1] = b1;
+      emask[tid][2] = b2;
+      emask[tid][3] = b3;
+    }
+
+    hsk_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    auto load_tile = [&](int n0, int k0) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int r = srow + pass * 32;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + r < n_rows) {
+          const float* src = Uw + (long long)urow[r] * D + k0 + scol;
+          if (VEC4) {
+            if (k0 + scol < D) va = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (k0 + scol + 0 < D) va.x = src[0];
+            if (k0 + scol + 1 < D) va.y = src[1];
+            if (k0 + scol + 2 < D) va.z = src[2];
+            if (k0 + scol + 3 < D) va.w = src[3];
+          }
+        }
+        if (n0 + r < item_count) {
+          const float* src = Iw + (item_begin + n0 + r) * (long long)D + k0 + scol;
+          if (VEC4) {
+            if (k0 + scol < D) vb = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (k0 + scol + 0 < D) vb.x = src[0];
+            if (k0 + scol + 1 < D) vb.y = src[1];
+            if (k0 + scol + 2 < D) vb.z = src[2];
+            if (k0 + scol + 3 < D) vb.w = src[3];
+          }
+        }
+        ra[pass] = va;
+        rbv[pass] = vb;
+      }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int r = srow + pass * 32;
+        *reinterpret_cast<float4*>(&As[r * FG_LDS_STRIDE + scol]) = ra[pass];
+        *reinterpret_cast<float4*>(&Bs[r * FG_LDS_STRIDE + scol]) = rbv[pass];
+      }
+    };
+    if (tile == t_lo) load_tile(n0, 0);   // later tiles: loaded under the previous tile's epilogue
+    store_tile();
+    __syncthreads();
+    for (int k0 = 0; k0 < D; k0 += FG_BK) {
+      const bool has_next = k0 + FG_BK < D;
+      if (has_next) load_tile(n0, k0 + FG_BK);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          a[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + l32) * FG_LDS_STRIDE + half * 16 + q * 4]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[j] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + j * 32 + l32) * FG_LDS_STRIDE + half * 16 + q * 4]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+      if (has_next) {
+        store_tile();
+        __syncthreads();
+      }
+    }
+
+    if (tile + 1 < t_hi) load_tile(n0 + FG_BN, 0);   // in flight during the epilogue and the compactions
+    // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cloc = wn * 64 + j * 32 + l32;
+        const int col = n0 + cloc;
+        if (col >= item_count) continue;
+        const float ib = Ib ? Ib[item_begin + col] : 0.f;
+        const uint32_t nid = ~(uint32_t)(item_begin + col);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rloc = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+          if (m0 + rloc >= n_rows) continue;
+          float o = acc[i][j][q];
+          if (Ub) o += ubias[rloc];   // reference order: += u_bias, += i_bias, += global_bias
+          if (Ib) o += ib;
+          if (gb) o += gbv;
+          // the common case ends here: one LDS read and one compare per score (NaN passes, as in torch.topk)
+          if (!(o < thr[rloc])) {
+            if ((emask[rloc][cloc >> 5] >> (cloc & 31)) & 1u) o = -INFINITY;
+            if (!(o < thr[rloc])) {
+              const int slot = atomicAdd(&cnt[rloc], 1);
+              cand[(long long)rloc * HSK_SEL_CAP + slot] = ((unsigned long long)fg_f2key(o) << 32) | nid;
+            }
+          }
+        }
+      }
+    __syncthreads();
+    // rows that the next tile could overflow: compact now (wave w owns rows 32w .. 32w+31)
+    for (int rr = 0; rr < 32; ++rr) {
+      const int rloc = wave * 32 + rr;
+      if (cnt[rloc] > HSK_SEL_TRIG) compact_row(rloc);
+    }
+    __syncthreads();
+  }
+
+  // final: every row down to its k best, sorted, out to this split's slice of the partial lists
+  for (int rr = 0; rr < 32; ++rr) {
+    const int rloc = wave * 32 + rr;
+    const int row = m0 + rloc;
+    if (row >= n_rows) continue;
+    compact_row(rloc);
+    const int keep = min(cnt[rloc], k);
+    sort_row(rloc, keep);
+    const long long dst = ((long long)split * n_rows + row) * k;
+    for (int j = lane; j < k; j += 64) {
+      float v = -INFINITY;
+      int32_t id = 0x7fffffff;   // pad of a split that holds fewer than k items: sorts behind everything real
+      if (j < keep) {
+        const unsigned long long c = srt[wave][j];
+        v = fg_key2f((uint32_t)(c >> 32));
+        id = (int32_t)(~(uint32_t)c);
+      }
+      part_vals[dst + j] = v;
+      part_idx[dst + j] = id;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// merge of the per-split lists: [n_parts, rows, k] -> [rows, k]  (same kernel contract as hsk_topk_merge)
+__global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ vals, const int32_t* __restrict__ idx,
+                                                     int n_parts, int rows, int k, int npad,
+                                                     float* __restrict__ out_vals, int32_t* __restrict__ out_idx) {
+  __shared__ unsigned long long cand[4096];
+  const int r = blockIdx.x;
+  const int total = n_parts * k;
+  for (int c = threadIdx.x; c < npad; c += 256) {
+    unsigned long long v = 0ull;
+    if (c < total) {
+      const int p = c / k, j = c - p * k;
+      const long long src = ((long long)p * rows + r) * k + j;
+      v = ((unsigned long long)fg_f2key(vals[src]) << 32) | (uint32_t)(~(uint32_t)idx[src]);
+    }
+    cand[c] = v;
+  }
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (npad >> 1); t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = cand[lo], b = cand[hi];
+        if ((a < b) == desc) {
+          cand[lo] = b;
+          cand[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < k; c += 256) {
+    const unsigned long long v = cand[c];
+    out_vals[(long long)r * k + c] = fg_key2f((uint32_t)(v >> 32));
+    out_idx[(long long)r * k + c] = (int32_t)(~(uint32_t)v);
+  }
+}
+
+// number of item splits: enough workgroups to fill the chip (~4 per CU), lists short enough for the merge
+static int hsk_fused_splits(int64_t n_rows, int64_t item_count, int64_t k) {
+  const int64_t row_blocks = hsk_ceil_div(n_rows, FG_BM), n_tiles = hsk_ceil_div(item_count, FG_BN);
+  int64_t s = hsk_ceil_div(1024, row_blocks);
+  s = std::min<int64_t>(s, 4096 / std::max<int64_t>(k, 1));   // the merge sorts <= 4096 keys per row
+  s = std::min<int64_t>(s, std::max<int64_t>(1, n_tiles / 8));   // a split of fewer than 8 tiles is all warm-up
+  s = std::max<int64_t>(s, 1);
+  if (s >= 8) s = s / 8 * 8;   // splits follow the XCDs: blockIdx.x % 8
+  return (int)s;
+}
+
+extern "C" int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count, int64_t k) {
+  if (n_rows <= 0 || item_count <= 0 || k <= 0 || k > HSK_SEL_KMAX) return -1;
+  const int64_t s = hsk_fused_splits(n_rows, item_count, k);
+  const int64_t row_blocks = hsk_ceil_div(n_rows, FG_BM);
+  const int64_t slab = row_blocks * s * FG_BM * HSK_SEL_CAP * 8;   // candidate slabs
+  const int64_t parts = s * n_rows * k * 8;                         // partial (value, id) lists
+  return hsk_align_up(slab, 256) + hsk_align_up(parts, 256) + 256;
+}
+
+extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_emb, const float* item_bias,
+                                      const float* user_bias, const float* global_bias, int64_t n_users,
+                                      int64_t n_items, int64_t dim, const int64_t* u_idx, int64_t n_rows,
+                                      int64_t item_begin, int64_t item_count, const int64_t* excl_indptr,
+                                      const int32_t* excl_indices, int64_t k, void* ws, int64_t ws_bytes,
+                                      float* out_vals, int32_t* out_idx, int32_t* status, hsk_stream_t stream_) {
+  HSK_REQUIRE(user_emb && item_emb && u_idx && ws && out_vals && out_idx, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_users > 0 && n_items > 0 && dim > 0, HSK_ERR_INVALID, "bad table shape");
+  HSK_REQUIRE(item_begin >= 0 && item_count > 0 && item_begin + item_count <= n_items, HSK_ERR_INVALID,
+              "item shard [%lld, +%lld) outside [0, %lld)", (long long)item_begin, (long long)item_count,
+              (long long)n_items);
+  HSK_REQUIRE(n_rows >= 0 && n_items < 0x7fffffff && n_rows < 0x7fffffff, HSK_ERR_INVALID, "bad n_rows");
+  HSK_REQUIRE((excl_indptr == nullptr) == (excl_indices == nullptr), HSK_ERR_INVALID,
+              "exclude CSR needs both indptr and indices");
+  HSK_REQUIRE(k >= 1 && k <= HSK_SEL_KMAX, HSK_ERR_UNSUPPORTED, "k %lld outside [1, %d]", (long long)k, HSK_SEL_KMAX);
+  HSK_REQUIRE(k <= item_count, HSK_ERR_INVALID, "k %lld > item_count %lld", (long long)k, (long long)item_count);
+  if (n_rows == 0) return HSK_OK;
+  const int64_t need = hsk_mf_eval_fused_ws_bytes(n_rows, item_count, k);
+  HSK_REQUIRE(ws_bytes >= need && ((uintptr_t)ws & 255) == 0, HSK_ERR_INVALID,
+              "workspace: %lld bytes (256-byte aligned) needed, %lld given", (long long)need, (long long)ws_bytes);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int S = hsk_fused_splits(n_rows, item_count, k);
+  const int64_t row_blocks = hsk_ceil_div(n_rows, FG_BM), n_tiles = hsk_ceil_div(item_count, FG_BN);
+  const int tiles_per_split = (int)hsk_ceil_div(n_tiles, S);
+  char* p = (char*)ws;
+  unsigned long long* slab = (unsigned long long*)p;
+  p += hsk_align_up(row_blocks * S * FG_BM * HSK_SEL_CAP * 8, 256);
+  float* part_vals = (float*)p;
+  int32_t* part_idx = (int32_t*)(p + (int64_t)S * n_rows * k * 4);
+  const unsigned grid = (unsigned)(hsk_ceil_div(row_blocks, 8) * 8 * S);
+  const bool vec4 = (dim % 4 == 0) && ((((uintptr_t)user_emb | (uintptr_t)item_emb) & 15) == 0);
+  float* pv = S == 1 ? out_vals : part_vals;
+  int32_t* pi = S == 1 ? out_idx : part_idx;
+  if (vec4)
+    k_score_topk<true><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
+                                                 (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
+                                                 tiles_per_split, excl_indptr, excl_indices, (int)k, S, slab, pv, pi,
+                                                 status);
+  else
+    k_score_topk<false><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
+                                                  (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
+                                                  tiles_per_split, excl_indptr, excl_indices, (int)k, S, slab, pv, pi,
+                                                  status);
+  HSK_LAUNCH_CHECK();
+  if (S > 1) {
+    int npad = 1;
+    while (npad < S * (int)k) npad <<= 1;
+    k_fused_merge<<<(unsigned)n_rows, 256, 0, stream>>>(part_vals, part_idx, S, (int)n_rows, (int)k, npad, out_vals,
+                                                        out_idx);
+    HSK_LAUNCH_CHECK();
+  }
+  return HSK_OK;
+}

@@ -523,7 +523,6 @@ def evaluate_item_sharded(comm: Comm, sharded, dataset, evaluator, chunk: Option
         chunk = min(2048 * W, U)
     chunk = max(W, (int(chunk) + W - 1) // W * W)         # chunk boundaries at multiples of W: a rank's rows of a chunk
     S = chunk // W                                         # are a contiguous slice of its shard; S users merged per rank
-    scores = torch.empty((chunk, I_loc), dtype=torch.float32, device=dev)
     send_u = torch.zeros((S, D), dtype=torch.float32, device=dev)
     all_u = torch.empty((W * S, D), dtype=torch.float32, device=dev)
     has_ub = sharded.user_bias is not None
@@ -571,7 +570,7 @@ def evaluate_item_sharded(comm: Comm, sharded, dataset, evaluator, chunk: Option
             u = torch.arange(n, device=dev)
             v, i, _ = hip_ops.mf_eval_topk(cu, sharded.item_emb, sharded.item_bias, cb, sharded.global_bias, u, kk,
                                            arr['excl_indptr'][lo: lo + n + 1], arr['excl_indices'], item_begin=lo_i,
-                                           item_count=I_loc, scores_ws=scores, status=status, item_shard=True,
+                                           item_count=I_loc, status=status, item_shard=True,
                                            n_items_global=I)
             b = bufs[ci & 1]
             inp = b['inp'].view(W * S, 2, k)

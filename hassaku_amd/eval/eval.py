@@ -101,11 +101,11 @@ def _hip_mf_eval(alg, dataset, evaluator: FullEvaluator, device, chunk: int):
     if dataset.n_items < k_max:
         raise ValueError(f'full evaluation needs at least {k_max} items (K_VALUES), got {dataset.n_items}')
     status = alg.status_word()
-    scores = torch.empty((min(chunk, dataset.n_users), dataset.n_items), dtype=torch.float32, device=device)
     for lo in range(0, dataset.n_users, chunk):
         u = torch.arange(lo, min(lo + chunk, dataset.n_users), device=device)
+        # top-k selected inside the score GEMM: no [chunk, n_items] matrix exists (hsk_mf_eval_topk_fused)
         _, ids, _ = hip_ops.mf_eval_topk(user_emb, item_emb, ib, ub, gb, u, k_max, arrays['excl_indptr'],
-                                         arrays['excl_indices'], scores_ws=scores, status=status)
+                                         arrays['excl_indices'], status=status)
         met = hip_ops.rank_metrics(ids, u, arrays['label_indptr'], arrays['label_indices'], ks)
         evaluator.eval_ranked(u, met, ks)
     alg.check_indices()
@@ -121,7 +121,10 @@ def evaluate_recommender_algorithm(alg: RecommenderAlgorithm, eval_loader, evalu
             raise RuntimeError('SGDMatrixFactorization evaluates on the HIP device only; move the model with '
                                '.to("cuda") (conf device: cuda)')
         with torch.no_grad():
-            chunk = max(int(getattr(eval_loader, 'batch_size', 256) or 256), 1024)
+            # wide catalogues select inside the GEMM (nothing of size chunk x n_items exists: the chunk only has to
+            # fill the chip); narrow ones materialise chunk x n_items scores
+            wide = dataset.n_items >= hip_ops.FUSED_TOPK_MIN_ITEMS
+            chunk = max(int(getattr(eval_loader, 'batch_size', 256) or 256), 16384 if wide else 4096)
             _hip_mf_eval(alg, dataset, evaluator, dev, chunk)
     else:
         iterator = eval_loader

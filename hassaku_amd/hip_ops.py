@@ -501,9 +501,21 @@ class BprMfFusedState:
 # ------------------------------------------------------------------------------------------------
 # evaluation
 # ------------------------------------------------------------------------------------------------
+FUSED_TOPK_MAX_K = 128     # hsk_mf_eval_topk_fused (HSK_SEL_KMAX)
+FUSED_TOPK_MIN_ITEMS = 32768   # below this many columns the warm-up of the in-GEMM selection (every row starts from
+                               # an empty list in every item split) costs more than writing the scores out: measured
+                               # 4.3 M users/s fused against 5.6 M materialised at 10 677 items, 0.62 M against 0.52 M
+                               # at 131 072
+_fused_ws = {}             # device -> scratch of the fused selection, grown on demand
+
+
 def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k, excl_indptr=None, excl_indices=None,
-                 item_begin=0, item_count=None, scores_ws=None, status=None, item_shard=False, n_items_global=None):
-    """Masked score matrix of one item shard and its top-k.  -> (vals [R,k] f32, idx [R,k] i32 global, scores).
+                 item_begin=0, item_count=None, scores_ws=None, status=None, item_shard=False, n_items_global=None,
+                 want_scores=None):
+    """Top-k of one item shard's masked scores.  -> (vals [R,k] f32, idx [R,k] i32 global, scores or None).
+    want_scores=False: the selection runs inside the score GEMM and the score matrix is never formed (scores = None).
+    want_scores=True (or a `scores_ws` buffer, k == 0, k > 128): the [R, item_count] matrix is materialised and
+    returned.  None (default): whichever is faster for the shard width (FUSED_TOPK_MIN_ITEMS); same results.
     item_shard=True: `item_emb` / `item_bias` are the PHYSICAL shard (rows item_begin .. item_begin + item_count of a
     catalogue of n_items_global items); the library is handed the virtual base of the catalogue and only ever
     dereferences the shard's rows (include/hassaku_hip.h)."""
@@ -531,6 +543,27 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
         _chk(excl_indices, torch.int32, 'excl_indices')
     R = u_idx.numel()
     dev = user_emb.device
+    if want_scores is None:
+        want_scores = scores_ws is not None or item_count < FUSED_TOPK_MIN_ITEMS
+    if not want_scores and scores_ws is None and 1 <= k <= FUSED_TOPK_MAX_K and R > 0:
+        need = lib.hsk_mf_eval_fused_ws_bytes(R, item_count, k)
+        if need <= 0:
+            raise ValueError('invalid fused top-k request')
+        ws = _fused_ws.get(dev)
+        if ws is None or ws.numel() < need:
+            ws = _fused_ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+        vals = torch.empty((R, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((R, k), dtype=torch.int32, device=dev)
+        p_emb, p_bias, n_all = _p(item_emb), _p(item_bias), n_items
+        if item_shard:
+            p_emb -= 4 * dim * item_begin
+            p_bias = None if p_bias is None else p_bias - 4 * item_begin
+            n_all = n_items_global
+        _lib.check(lib.hsk_mf_eval_topk_fused(_p(user_emb), p_emb, p_bias, _p(user_bias), _p(global_bias), n_users,
+                                              n_all, dim, _p(u_idx), R, item_begin, item_count, _p(excl_indptr),
+                                              _p(excl_indices), k, _p(ws), ws.numel(), _p(vals), _p(idx), _p(status),
+                                              _stream()), 'hsk_mf_eval_topk_fused')
+        return vals, idx, None
     if scores_ws is None:
         scores_ws = torch.empty((R, item_count), dtype=torch.float32, device=dev)
     else:

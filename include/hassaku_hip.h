@@ -401,6 +401,22 @@ int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, const float* 
                      int64_t k, float* scores_ws, float* out_vals, int32_t* out_idx,
                      int32_t* status, hsk_stream_t stream);
 
+/*
+ * The same result WITHOUT the score matrix: the top-k selection runs inside the score GEMM (per-row thresholds and
+ * candidate lists, csrc/hsk_eval_fused.hip), so nothing of size n_rows x item_count is ever written -- at 131 072
+ * items that matrix is 1 GB per 2048 users.  k <= 128.  ws: hsk_mf_eval_fused_ws_bytes(n_rows, item_count, k) bytes of
+ * device scratch, 256-byte aligned.  out_vals / out_idx exactly as hsk_mf_eval_topk returns them.
+ */
+int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count, int64_t k);
+int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_emb, const float* item_bias,
+                           const float* user_bias, const float* global_bias,
+                           int64_t n_users, int64_t n_items, int64_t dim,
+                           const int64_t* u_idx, int64_t n_rows,
+                           int64_t item_begin, int64_t item_count,
+                           const int64_t* excl_indptr, const int32_t* excl_indices,
+                           int64_t k, void* ws, int64_t ws_bytes, float* out_vals, int32_t* out_idx,
+                           int32_t* status, hsk_stream_t stream);
+
 /* top-k of each row of a dense [rows, cols] fp32 matrix (leading dimension ld); indices int64
  * (torch.topk dtype); order (value desc, index asc).  Replaces logits.topk(k) (eval/eval.py:63). */
 int hsk_topk_dense(const float* logits, int64_t rows, int64_t cols, int64_t ld, int64_t k,

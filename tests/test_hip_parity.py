@@ -521,7 +521,8 @@ def test_eval_topk_metrics_vs_golden(ops, split):
     l_ptr, l_idx = csr_from_pairs(fx[split], n_users)
     u = fx[f'{split}.u']
     status = ops.new_status('cuda')
-    vals, ids, scores = ops.mf_eval_topk(U, I, Ib, Ub, gb, dev(u), 100, dev(e_ptr), dev(e_idx), status=status)
+    vals, ids, scores = ops.mf_eval_topk(U, I, Ib, Ub, gb, dev(u), 100, dev(e_ptr), dev(e_idx), status=status,
+                                         want_scores=True)
     ops.raise_on_status(status)
     sc, ref = scores.cpu().numpy(), fx[f'{split}.masked_logits']
     assert np.array_equal(np.isinf(sc), np.isinf(ref))
@@ -549,6 +550,51 @@ def test_eval_topk_metrics_vs_golden(ops, split):
                 got[f'group_{g}_{nm}@{k}'] = met[grp == g, t, j].astype(np.float64).mean()
     for name, val in zip(names, fx[f'{split}.metric_values']):
         assert abs(got[name] - val) <= 1e-6 + 1e-4 * abs(val), name
+
+
+@pytest.mark.parametrize('shape', [
+    # (rows, n_users, n_items, D, k)
+    (300, 300, 5000, 512, 100),      # D = 512 (BASELINE configs[2-3]), several item splits + the split merge
+    (130, 200, 1000, 30, 100),       # D % 4 != 0: scalar staging loads; one split of 8 tiles
+    (70, 70, 40000, 64, 100),        # long rows: thresholds, appends and repeated compactions
+    (257, 400, 300, 128, 5),         # small k, three row blocks (the last one ragged)
+    (64, 64, 129, 16, 100),          # two tiles, the second with a single column
+])
+def test_fused_topk_equals_materialised_topk(ops, shape):
+    """Top-k selected inside the score GEMM (no score matrix) == top-k of the materialised, masked score matrix:
+    same values, same ids, same order -- with biases, exclusions (one user with fewer than k admissible items: the
+    -inf entries fill up, lowest id first), exact ties (duplicated item rows) and an item range."""
+    R, n_users, n_items, D, k = shape
+    g = torch.Generator(device='cuda').manual_seed(7)
+    U = torch.randn(n_users, D, device='cuda', generator=g) * 0.3
+    I = torch.randn(n_items, D, device='cuda', generator=g) * 0.3
+    I[n_items // 2: n_items // 2 + 20] = I[:20]              # exact ties between items far apart
+    Ib = torch.randn(n_items, device='cuda', generator=g) * 0.1
+    Ib[n_items // 2: n_items // 2 + 20] = Ib[:20]
+    Ub = torch.randn(n_users, device='cuda', generator=g) * 0.1
+    gb = torch.tensor([0.3], device='cuda')
+    rng = np.random.RandomState(5)
+    pairs = np.argwhere(rng.rand(n_users, n_items) < min(0.05, 300.0 / n_items))
+    if n_items > k:       # user 1 keeps only k - 30 admissible items
+        keep = rng.choice(n_items, size=max(k - 30, 1), replace=False)
+        rest = np.setdiff1d(np.arange(n_items), keep)
+        pairs = np.concatenate([pairs[pairs[:, 0] != 1], np.stack([np.ones_like(rest), rest], axis=1)])
+    e_ptr, e_idx = csr_from_pairs(pairs, n_users)
+    u = torch.from_numpy(rng.randint(0, n_users, size=R).astype(np.int64)).cuda()
+    u[0] = 1
+    for lo, cnt in ((0, n_items), (n_items // 3, n_items - n_items // 3 - 7)):
+        kk = min(k, cnt)
+        v_ref, i_ref, sc = ops.mf_eval_topk(U, I, Ib, Ub, gb, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo,
+                                            item_count=cnt, want_scores=True)
+        v, i, none = ops.mf_eval_topk(U, I, Ib, Ub, gb, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
+                                      want_scores=False)
+        assert none is None and sc is not None
+        assert torch.equal(i, i_ref), (lo, cnt, int((i != i_ref).sum()))
+        assert torch.equal(v, v_ref)
+    # without an exclusion CSR and without biases
+    v_ref, i_ref, _ = ops.mf_eval_topk(U, I, None, None, None, u, min(k, n_items), want_scores=True)
+    v, i, _ = ops.mf_eval_topk(U, I, None, None, None, u, min(k, n_items), want_scores=False)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
 
 
 def test_eval_item_shards_merge_to_global_topk(ops):
