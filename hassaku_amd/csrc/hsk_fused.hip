@@ -431,9 +431,11 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
         urow_index, w.g_s, w.perm, w.offsets, I, K, D, c, gI_out, gIb_out);
     return;
   }
-  static const int force_vs = getenv("HSK_ITEM_VS") ? atoi(getenv("HSK_ITEM_VS")) : 0;      // tuning knobs
-  static const int ipw = getenv("HSK_ITEM_IPW") ? atoi(getenv("HSK_ITEM_IPW")) : 1;
-  const int vs = force_vs == 2 ? 2 : (D % 4 == 0) ? 4 : 2;
+  // slice width: 64 lanes x VS floats, the widest vector the row alignment allows (narrower slices and more items per
+  // wave were measured slower: 112 / 84-88 us against 81 us at the ml10m shape)
+  constexpr int VSC = (V == 4) ? 4 : 2;
+  const int ipw = 1;
+  const int vs = VSC;
   const int n_sl = (int)hsk_ceil_div(D, 64 * vs);
   // merged launch at a small batch: whole-row item workgroups (n_slices_pad = 0 tells the kernel), see hsk_item_row_body
   static const int rows_on = getenv("HSK_ITEM_ROWS") ? atoi(getenv("HSK_ITEM_ROWS")) : 1;
@@ -459,27 +461,23 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
     int n_ahead_oct = ahead.coo_user ? (int)hsk_ceil_div(hsk_ceil_div(ahead.n, 4), 8) : 0;
     n_ahead_oct = std::min(n_ahead_oct, item_oct);
     const int stride = n_ahead_oct ? item_oct / n_ahead_oct : 0;
-#define HSK_ITEM_USER(VS, GEN, LZ)                                                                              \
-  k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)(nub + 8 * n_ahead_oct), 256, 0, stream>>>(            \
-      ia, *ua, nub, dense, ahead, n_ahead_oct, stride)
-    if (vs == 4) {
-      if (gen) { if (lazy) HSK_ITEM_USER(4, true, true); else HSK_ITEM_USER(4, true, false); }
-      else     { if (lazy) HSK_ITEM_USER(4, false, true); else HSK_ITEM_USER(4, false, false); }
-    } else {
-      if (gen) { if (lazy) HSK_ITEM_USER(2, true, true); else HSK_ITEM_USER(2, true, false); }
-      else     { if (lazy) HSK_ITEM_USER(2, false, true); else HSK_ITEM_USER(2, false, false); }
-    }
+    if (!whole_rows) n_ahead_oct = 0;   // the ahead workgroups belong to the small-batch flavour
+#define HSK_ITEM_USER(VS, GEN, LZ)                                                                             \
+  do {                                                                                                         \
+    if (whole_rows)                                                                                            \
+      k_item_user_small<V, NCH, FULL, GEN, LZ><<<nblk + (unsigned)(nub + 8 * n_ahead_oct), 256, 0, stream>>>(    \
+          ia, *ua, nub, dense, ahead, n_ahead_oct, stride);                                                    \
+    else                                                                                                       \
+      k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)nub, 256, 0, stream>>>(ia, *ua, nub, dense);     \
+  } while (0)
+    if (gen) { if (lazy) HSK_ITEM_USER(VSC, true, true); else HSK_ITEM_USER(VSC, true, false); }
+    else     { if (lazy) HSK_ITEM_USER(VSC, false, true); else HSK_ITEM_USER(VSC, false, false); }
 #undef HSK_ITEM_USER
     return;
   }
 #define HSK_ITEM_SLICED(VS, GEN, LZ) k_item_update_sliced<APPLY, VS, GEN, LZ><<<nblk, 256, 0, stream>>>(ia)
-  if (vs == 4) {
-    if (gen) { if (lazy) HSK_ITEM_SLICED(4, true, true); else HSK_ITEM_SLICED(4, true, false); }
-    else     { if (lazy) HSK_ITEM_SLICED(4, false, true); else HSK_ITEM_SLICED(4, false, false); }
-  } else {
-    if (gen) { if (lazy) HSK_ITEM_SLICED(2, true, true); else HSK_ITEM_SLICED(2, true, false); }
-    else     { if (lazy) HSK_ITEM_SLICED(2, false, true); else HSK_ITEM_SLICED(2, false, false); }
-  }
+  if (gen) { if (lazy) HSK_ITEM_SLICED(VSC, true, true); else HSK_ITEM_SLICED(VSC, true, false); }
+  else     { if (lazy) HSK_ITEM_SLICED(VSC, false, true); else HSK_ITEM_SLICED(VSC, false, false); }
 #undef HSK_ITEM_SLICED
 }
 

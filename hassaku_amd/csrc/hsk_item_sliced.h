@@ -245,9 +245,28 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
 // `stride` octets of item workgroups (whole octets, so the item workgroups keep blockIdx % 8 == their own index % 8,
 // i.e. their XCD affinity): the replay is VALU work that should run beside the memory-bound item waves, not in front
 // of them.
+// Two flavours, two kernels: the row body's registers would cost the D-sliced, latency-bound flavour its occupancy
+// (measured: 90 -> 106 us at the ml10m shape), and the three argument blocks push the scalar registers past what 8
+// waves per SIMD allow -- hence the explicit occupancy request on the large-batch kernel.
 template <int V, int NCH, bool FULL, int VS, bool GEN, bool LAZYI>
-__global__ __launch_bounds__(256) void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks,
-                                                   int dense_users, hsk_ahead_args aa, int n_ahead_oct, int stride) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int dense_users) {
+  const int bid = (int)blockIdx.x;
+  if (bid < n_user_blocks) {
+    if (dense_users)
+      hsk_user_update_dense_body<V, NCH, FULL, GEN>(ua, bid);
+    else
+      hsk_user_update_lazy_body<V, NCH, FULL, GEN>(ua, bid);
+    return;
+  }
+  hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, bid - n_user_blocks);
+}
+
+// small batches: whole-row item workgroups, interleaved with the ahead workgroups
+template <int V, int NCH, bool FULL, bool GEN, bool LAZYI>
+__global__ __launch_bounds__(256) void k_item_user_small(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks,
+                                                         int dense_users, hsk_ahead_args aa, int n_ahead_oct,
+                                                         int stride) {
   const int bid = (int)blockIdx.x;
   if (bid < n_user_blocks) {
     if (dense_users)
@@ -271,8 +290,5 @@ __global__ __launch_bounds__(256) void k_item_user(hsk_item_args ia, hsk_user_la
       item_oct = n_ahead_oct * stride + (q - full);
     }
   }
-  if (ia.n_slices_pad == 0)   // small batches: whole rows (see hsk_item_row_body)
-    hsk_item_row_body<V, NCH, FULL, GEN, LAZYI>(ia, item_oct * 8 + r);
-  else
-    hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, item_oct * 8 + r);
+  hsk_item_row_body<V, NCH, FULL, GEN, LAZYI>(ia, item_oct * 8 + r);
 }

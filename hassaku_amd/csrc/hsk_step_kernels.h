@@ -627,6 +627,84 @@ __device__ __forceinline__ void hsk_resolve_step(const hsk_step_desc* desc, int 
   }
 }
 
+// AdamW on one user row, one 64-lane chunk at a time ((p, m, v, g) of a whole row in registers would cost the item
+// workgroups that share the launch their occupancy).  Gradient = dUb[b] + the rows of the user's further entries in
+// the batch (n entries in all), added in ascending b: usually those registered with the owner (dupcnt / duplist, in
+// arrival order: ranked here), otherwise the batch is scanned.  n == 0: no gradient (dense sweep over an idle row).
+template <int V, int NCH, bool FULL, bool GEN>
+__device__ __forceinline__ void hsk_user_row_chunks(const hsk_user_lazy_args& a, int row, int b, int n,
+                                                    const float* __restrict__ psrc, const float* __restrict__ msrc,
+                                                    const float* __restrict__ vsrc, float* __restrict__ prow,
+                                                    float* __restrict__ mrow, float* __restrict__ vrow, int lane) {
+  const int B = a.B, D = a.D;
+  int dl[HSK_DUP_MAX];
+  int nd_list = 0;
+  bool scan = false;
+  if (n > 1) {
+    scan = true;
+    if (a.dupcnt) {
+      const int nd = hsk_uniform_i(a.dupcnt[b]);
+      if (lane == 0) a.dupcnt[b] = 0;
+      if (nd == n - 1 && nd <= HSK_DUP_MAX) {
+        const int mine = (lane < nd) ? a.duplist[b * HSK_DUP_MAX + lane] : 0x7fffffff;
+        int rank = 0;
+#pragma unroll
+        for (int k = 0; k < HSK_DUP_MAX; ++k) rank += (k < nd && hsk_readlane_i(mine, k) < mine) ? 1 : 0;
+#pragma unroll
+        for (int r = 0; r < HSK_DUP_MAX; ++r) {
+          const unsigned long long mm = __ballot(lane < nd && rank == r);
+          dl[r] = (r < nd) ? hsk_readlane_i(mine, __builtin_ctzll(mm | (1ull << 63))) : 0;
+        }
+        nd_list = nd;
+        scan = false;
+      }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < NCH; ++cc) {
+    const int off = (cc * 64 + lane) * V;
+    const bool live = FULL || off < D;
+    hsk_vec<V> p = hsk_zero<V>(), m = hsk_zero<V>(), v = hsk_zero<V>(), g = hsk_zero<V>();
+    if (live) {
+      p = hsk_ldg<V>(psrc + off);
+      m = hsk_ldg<V>(msrc + off);
+      v = hsk_ldg<V>(vsrc + off);
+      if (n > 0) g = hsk_ldg<V>(a.dUb + (long long)b * D + off);
+    }
+#pragma unroll
+    for (int r = 0; r < HSK_DUP_MAX; ++r)
+      if (r < nd_list && live) {
+        const hsk_vec<V> t = hsk_ldg<V>(a.dUb + (long long)dl[r] * D + off);
+#pragma unroll
+        for (int q = 0; q < V; ++q) g.v[q] += t.v[q];
+      }
+    if (scan) {
+      int found = 1;
+      for (int g0 = (b / 64) * 64; g0 < B && found < n; g0 += 64) {
+        const int bb = g0 + lane;
+        unsigned long long mask = __ballot(bb < B && bb > b && a.u32[bb] == row);
+        while (mask) {
+          const int j = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          if (live) {
+            const hsk_vec<V> t = hsk_ldg<V>(a.dUb + (long long)(g0 + j) * D + off);
+#pragma unroll
+            for (int q = 0; q < V; ++q) g.v[q] += t.v[q];
+          }
+          ++found;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.v[q], m.v[q], v.v[q], g.v[q], a.c);
+    if (live) {
+      hsk_stg<V>(prow + off, p);
+      hsk_stg<V>(mrow + off, m);
+      hsk_stg<V>(vrow + off, v);
+    }
+  }
+}
+
 template <int V, int NCH, bool FULL, bool GEN>
 __device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_args& a0, int bid) {
   hsk_user_lazy_args a = a0;
@@ -642,9 +720,9 @@ __device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_ar
   if (b >= B) return;
   const int row = hsk_uniform_i(a.u32[b]);
   if (row < 0) return;  // empty exchange slot (row-sharded mode)
-  using Row = hsk_row<V, NCH>;
-  // the row loads are issued together with the owner / count lookups (one memory latency instead of two); a
-  // duplicate entry (not the owner) throws them away -- ~1 % of the entries at the BASELINE shapes
+  const int own = hsk_uniform_i(a.owner[row]);
+  if (own != b) return;   // a duplicate entry of a user somebody else owns
+  const int n = hsk_uniform_i(a.cnt[row]);
   float* prow = a.Uw + (long long)row * D;
   float* mrow = a.mU + (long long)row * D;
   float* vrow = a.vU + (long long)row * D;
@@ -652,23 +730,10 @@ __device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_ar
   // current (p, m, v) of the owner entry in ucur / mcur / vcur[b] (the table row itself is rewritten only here)
   const int done = a.tab ? hsk_uniform_i(a.last_step[row]) : step - 1;
   const bool behind = done < step - 1;
-  Row p, m, v;
-  hsk_row_load<V, NCH, FULL>(p, behind ? a.ucur + (long long)b * D : prow, lane, D);
-  hsk_row_load<V, NCH, FULL>(m, behind ? a.mcur + (long long)b * D : mrow, lane, D);
-  hsk_row_load<V, NCH, FULL>(v, behind ? a.vcur + (long long)b * D : vrow, lane, D);
-  const int own = hsk_uniform_i(a.owner[row]);
-  const int n = hsk_uniform_i(a.cnt[row]);
-  if (own != b) return;
-  Row g;
-  float dummy = 0.f;
-  hsk_user_grad<V, NCH, FULL>(g, dummy, row, b, n, a.dUb, a.u32, B, D, lane, a.dupcnt, a.duplist);
-#pragma unroll
-  for (int cc = 0; cc < NCH; ++cc)
-#pragma unroll
-    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], a.c);
-  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  const float* psrc = behind ? a.ucur + (long long)b * D : prow;
+  const float* msrc = behind ? a.mcur + (long long)b * D : mrow;
+  const float* vsrc = behind ? a.vcur + (long long)b * D : vrow;
+  hsk_user_row_chunks<V, NCH, FULL, GEN>(a, row, b, n, psrc, msrc, vsrc, prow, mrow, vrow, lane);
   if (lane == 0) {
     if (a.Ub) {
       float pb = a.Ub[row], mb = a.mUb[row], vb = a.vUb[row];
@@ -706,32 +771,18 @@ __device__ __forceinline__ void hsk_user_update_dense_body(const hsk_user_lazy_a
   const int lane = hsk_lane();
   const int row = bid * 4 + hsk_uniform_i(threadIdx.x >> 6);
   if (row >= U) return;
-  using Row = hsk_row<V, NCH>;
   float* prow = a.Uw + (long long)row * D;
   float* mrow = a.mU + (long long)row * D;
   float* vrow = a.vU + (long long)row * D;
-  Row p, m, v, g;
-  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
   const int n = hsk_uniform_i(a.cnt[row]);
-  if (n > 0) {
-    float dummy = 0.f;
-    hsk_user_grad<V, NCH, FULL>(g, dummy, row, hsk_uniform_i(a.owner[row]), n, a.dUb, a.u32, a.B, D, lane);
-    if (lane == 0) {
-      a.owner[row] = HSK_OWNER_NONE;
-      a.cnt[row] = 0;
-    }
-  } else {
-    hsk_row_zero(g);
+  const int b0 = n > 0 ? hsk_uniform_i(a.owner[row]) : 0;
+  hsk_user_lazy_args a2 = a;
+  a2.dupcnt = nullptr;   // the dense path never registered duplicates: batch scan
+  hsk_user_row_chunks<V, NCH, FULL, GEN>(a2, row, b0, n, prow, mrow, vrow, prow, mrow, vrow, lane);
+  if (n > 0 && lane == 0) {
+    a.owner[row] = HSK_OWNER_NONE;
+    a.cnt[row] = 0;
   }
-#pragma unroll
-  for (int cc = 0; cc < NCH; ++cc)
-#pragma unroll
-    for (int q = 0; q < V; ++q) hsk_adamw_update<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], g.c[cc].v[q], a.c);
-  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
-  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
-  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
   if (a.Ub && lane == 0) {
     // d loss / d user_bias is identically 0 under BPR (it cancels in s_pos - s_neg)
     float pb = a.Ub[row], mb = a.mUb[row], vb = a.vUb[row];
