@@ -118,22 +118,26 @@ SIGNATURES = {
 }
 
 
-def load():
-    """Load the shared library once and attach the prototypes.  Raises if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
+def open_library(path):
+    """ctypes handle of one build of the library with every prototype attached."""
+    if not os.path.isfile(path):
         raise RuntimeError(
-            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             f'or `make -C hassaku_amd/csrc`.  There is no CPU fallback for the HIP path.')
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
     return lib
+
+
+def load():
+    """Load the shared library once and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        _lib = open_library(LIB_PATH)
+    return _lib
 
 
 def check(rc: int, what: str = ''):

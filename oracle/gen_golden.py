@@ -237,6 +237,51 @@ def gen_g3():
         np.savez_compressed(os.path.join(OUT, 'g3_eval.npz'), **fx)
 
 
+def gen_g3_d512():
+    """G3 at the BASELINE embedding size and a catalogue wide enough (> 4096 items) for the wide-row top-k paths:
+    D = 512, 4224 items, 48 users.  The item table alone is 8.6 MB, so the fixture does not carry the parameters:
+    they are the reference's own seeded initialisation (torch.manual_seed(64), scaled as below) -- which
+    hassaku_amd reproduces bit for bit (tests/test_host_logic.py) -- and the fixture holds a checksum of them next to
+    the reference's outputs."""
+    from algorithms.sgd_alg import SGDMatrixFactorization
+    from data.dataset import FullEvalDataset
+    from eval.eval import evaluate_recommender_algorithm, FullEvaluator
+    from torch.utils.data import DataLoader
+    with tempfile.TemporaryDirectory() as tmp:
+        data = toy_dataset(tmp, n_users=48, n_items=4224, n_inter=6000, n_groups=2, seed=9)
+        ds = FullEvalDataset(tmp, 'val')
+        ds.exclude_data = _ExcludeAdapter(ds.exclude_data)
+        loader = DataLoader(ds, batch_size=16, num_workers=0)
+        torch.manual_seed(64)
+        model = SGDMatrixFactorization(data.n_users, data.n_items, 512, False, True, False)
+        with torch.no_grad():  # spread the scores out (init std is 0.1/D)
+            model.user_embeddings.weight.mul_(2000.)
+            model.item_embeddings.weight.mul_(2000.)
+        captured = {}
+
+        class Spy(FullEvaluator):
+            def eval_batch(self, u_idxs, logits, y_true):
+                captured.setdefault('u', []).append(u_idxs.numpy().copy())
+                captured.setdefault('logits', []).append(logits.numpy().copy())
+                captured.setdefault('topk', []).append(logits.topk(100).indices.numpy().copy())
+                super().eval_batch(u_idxs, logits, y_true)
+
+        ev = Spy(aggr_by_group=True, n_groups=ds.n_user_groups, user_to_user_group=ds.user_to_user_group)
+        metrics = evaluate_recommender_algorithm(model, loader, ev, 'cpu', False)
+        sd = state_np(model)
+        fx = {'n_users': data.n_users, 'n_items': data.n_items, 'dim': 512, 'seed': 64, 'scale': 2000.0,
+              'train': data.train, 'val': data.val, 'user_group': data.user_group,
+              'param_checksum': np.array([np.float64(v.astype(np.float64).sum()) for k, v in sorted(sd.items())]),
+              'param_names': np.array(sorted(sd)),
+              'item_row_17': sd['item_embeddings.weight'][17], 'user_row_5': sd['user_embeddings.weight'][5],
+              'val.u': np.concatenate(captured['u']), 'val.masked_logits': np.concatenate(captured['logits']),
+              'val.top100': np.concatenate(captured['topk']),
+              'val.metric_names': np.array(sorted(metrics)),
+              'val.metric_values': np.array([metrics[k] for k in sorted(metrics)], dtype=np.float64)}
+        print('g3_d512 ndcg@10', metrics['ndcg@10'], 'n metrics', len(metrics))
+        np.savez_compressed(os.path.join(OUT, 'g3_eval_d512.npz'), **fx)
+
+
 def gen_g4():
     from algorithms.sgd_alg import SGDMatrixFactorization
     from data.dataloader import TrainDataLoader, NegativeSampler
@@ -448,8 +493,14 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     import_reference()
     torch.set_num_threads(1)
+    only = sys.argv[1:]          # e.g. `gen_golden.py g3_d512`: regenerate a single fixture
+    if only:
+        for name in only:
+            globals()['gen_' + name]()
+        sys.exit(0)
     gen_g1()
     gen_g3()
+    gen_g3_d512()
     gen_g4()
     gen_g5()
     gen_g6()

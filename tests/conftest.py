@@ -75,6 +75,26 @@ PARAM_KEYS = {  # state_dict key -> short name used by the oracle / fused state
     'item_bias.weight': 'item_bias', 'user_bias.weight': 'user_bias', 'global_bias': 'global_bias'}
 
 
+def g3_d512_params(fx):
+    """The parameters of the G3-D512 fixture: not stored (8.7 MB) but regenerated -- the reference's seeded
+    initialisation, which hassaku_amd's model reproduces bit for bit -- and verified against the fixture's checksums
+    and the two rows it does carry."""
+    import torch
+    from hassaku_amd.algorithms.sgd_alg import SGDMatrixFactorization
+    torch.manual_seed(int(fx['seed']))
+    m = SGDMatrixFactorization(int(fx['n_users']), int(fx['n_items']), int(fx['dim']), False, True, False)
+    with torch.no_grad():
+        m.user_embeddings.weight.mul_(float(fx['scale']))
+        m.item_embeddings.weight.mul_(float(fx['scale']))
+    sd = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    assert [str(x) for x in fx['param_names']] == sorted(sd)
+    for name, chk in zip(sorted(sd), fx['param_checksum']):
+        assert np.float64(sd[name].astype(np.float64).sum()) == chk, name
+    assert np.array_equal(sd['item_embeddings.weight'][17], fx['item_row_17'])
+    assert np.array_equal(sd['user_embeddings.weight'][5], fx['user_row_5'])
+    return sd['user_embeddings.weight'], sd['item_embeddings.weight'], sd['item_bias.weight'].reshape(-1)
+
+
 @pytest.fixture(scope='session')
 def oracle():
     from oracle import oracle as orc

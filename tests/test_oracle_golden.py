@@ -132,6 +132,27 @@ def test_eval_scores_topk_metrics_match_reference(oracle, split):
         assert abs(m[name] - val) <= 1e-6 + 1e-5 * abs(val), name
 
 
+def test_eval_d512_wide_catalogue_matches_reference(oracle):
+    """G3 at D = 512 over 4224 items (the BASELINE embedding size, a catalogue wide enough for the wide-row top-k)."""
+    from conftest import g3_d512_params
+    fx = load_golden('g3_eval_d512.npz')
+    U, I, Ib = g3_d512_params(fx)
+    n_users = int(fx['n_users'])
+    e_ptr, e_idx = csr_from_pairs(fx['train'], n_users)
+    l_ptr, l_idx = csr_from_pairs(fx['val'], n_users)
+    sc = oracle.eval_scores(U, I, Ib, None, None, fx['val.u'], e_ptr, e_idx)
+    ref = fx['val.masked_logits']
+    assert np.array_equal(np.isinf(sc), np.isinf(ref))
+    fin = ~np.isinf(ref)
+    np.testing.assert_allclose(sc[fin], ref[fin], rtol=RTOL, atol=2e-6 * np.abs(ref[fin]).max())
+    _, ids = oracle.topk(ref, 100)
+    assert np.array_equal(ids, fx['val.top100'])
+    m = oracle.full_eval_metrics(U, I, Ib, None, None, np.arange(n_users), e_ptr, e_idx, l_ptr, l_idx,
+                                 user_group=fx['user_group'], n_groups=2, batch=16)
+    for name, val in zip([str(x) for x in fx['val.metric_names']], fx['val.metric_values']):
+        assert abs(m[name] - val) <= 1e-6 + 1e-5 * abs(val), name
+
+
 def test_replay_of_reference_fit_matches(oracle):
     """G4: replay the exact batch stream the reference loader produced through the oracle trainer."""
     fx = load_golden('g4_fit.npz')
