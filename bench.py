@@ -171,7 +171,7 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     replayed = comm is None and B < 2048 and not all_stages and prefetch
     names = ('prep', 'scan', 'scatter', 'fwd', 'item', 'user', 'finish') if comm is None else ('fwd', 'item', 'user')
     if not replayed:
-        st.enable_timing(names if all_stages else ('fwd',), every=1 if (all_stages or steps < 64) else 8)
+        st.enable_timing(names if all_stages else ('fwd',), every=1 if (all_stages or steps <= 64) else 8)
     fence()
     t0 = time.perf_counter()
     run(steps, warmup)
@@ -395,6 +395,7 @@ def main():
     ap.add_argument('--lazy-users', action='store_true', help='lazy, exact user AdamW whatever the table size')
     ap.add_argument('--time-all-stages', action='store_true', help='event-time every stage (perturbs the step time)')
     ap.add_argument('--only', action='store_true', help='headline workload only: no extra workloads, no eval legs')
+    ap.add_argument('--eval-only', default=None, choices=sorted(EVAL_SHAPES), help='only the evaluation leg of this shape (profiling)')
     ap.add_argument('--sharded', action='store_true', help='N=1 through the multi-GPU code path (1-rank process group)')
     args = ap.parse_args()
 
@@ -427,6 +428,15 @@ def main():
             dist.init_process_group(args.backend)
         comm = Comm()
 
+    if args.eval_only:
+        out = {'eval': {args.eval_only: run_eval(args.eval_only, device, comm)}}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if comm is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     r = run_training(args.workload, device, args.steps, args.warmup, comm=comm, prefetch=not args.no_prefetch,
                      lazy_users=False if args.dense_users else True if args.lazy_users else 'auto',
                      all_stages=args.time_all_stages)

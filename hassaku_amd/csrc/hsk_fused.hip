@@ -461,14 +461,16 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
     int n_ahead_oct = ahead.coo_user ? (int)hsk_ceil_div(hsk_ceil_div(ahead.n, 4), 8) : 0;
     n_ahead_oct = std::min(n_ahead_oct, item_oct);
     const int stride = n_ahead_oct ? item_oct / n_ahead_oct : 0;
-    if (!whole_rows) n_ahead_oct = 0;   // the ahead workgroups belong to the small-batch flavour
+    const int nab_big = ahead.coo_user ? (int)hsk_align_up(hsk_ceil_div(ahead.n, 4), 8) : 0;   // large-batch kernel
+
 #define HSK_ITEM_USER(VS, GEN, LZ)                                                                             \
   do {                                                                                                         \
     if (whole_rows)                                                                                            \
       k_item_user_small<V, NCH, FULL, GEN, LZ><<<nblk + (unsigned)(nub + 8 * n_ahead_oct), 256, 0, stream>>>(    \
           ia, *ua, nub, dense, ahead, n_ahead_oct, stride);                                                    \
     else                                                                                                       \
-      k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)nub, 256, 0, stream>>>(ia, *ua, nub, dense);     \
+      k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)(nub + (LZ ? nab_big : 0)), 256, 0, stream>>>(   \
+          ia, *ua, nub, dense, ahead, LZ ? nab_big : 0);                                                       \
   } while (0)
     if (gen) { if (lazy) HSK_ITEM_USER(VSC, true, true); else HSK_ITEM_USER(VSC, true, false); }
     else     { if (lazy) HSK_ITEM_USER(VSC, false, true); else HSK_ITEM_USER(VSC, false, false); }
@@ -768,7 +770,9 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       // replay inside the forward, so large batches keep it there.
       hsk_ahead_args aa = {};
       static const int ahead_on = getenv("HSK_AHEAD") ? atoi(getenv("HSK_AHEAD")) : 1;
-      if (lazy && aux && ahead_on && hsk_pf_early(B) && (aux->pf_valid || aux->hint_valid)) {
+      // (huge catalogues with lazy item AdamW: the item launch is AdamW traffic on the touched rows, memory-bound with
+      // idle VALUs, so the replay hides there as well)
+      if (lazy && aux && ahead_on && (hsk_pf_early(B) || st->lazy_items) && (aux->pf_valid || aux->hint_valid)) {
         const bool pf = aux->pf_valid;
         aa = hsk_ahead_args{st->coo_user, pf ? aux->pf_order : aux->hint_order, pf ? aux->pf_start : aux->hint_start,
                             (int)(pf ? aux->pf_batch : aux->hint_batch), w.stamp, w.claim, st->user_emb, st->m_user_emb,

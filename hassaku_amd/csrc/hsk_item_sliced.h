@@ -248,9 +248,12 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
 // Two flavours, two kernels: the row body's registers would cost the D-sliced, latency-bound flavour its occupancy
 // (measured: 90 -> 106 us at the ml10m shape), and the three argument blocks push the scalar registers past what 8
 // waves per SIMD allow -- hence the explicit occupancy request on the large-batch kernel.
+// LAZYI (huge catalogues, lazy item AdamW): the launch is AdamW traffic on the touched item rows with the VALUs idle,
+// so n_ahead_blocks workgroups of hsk_user_ahead_body ride in front of the item workgroups here too.
 template <int V, int NCH, bool FULL, int VS, bool GEN, bool LAZYI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int dense_users) {
+void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int dense_users, hsk_ahead_args aa,
+                 int n_ahead_blocks) {
   const int bid = (int)blockIdx.x;
   if (bid < n_user_blocks) {
     if (dense_users)
@@ -259,7 +262,11 @@ void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int
       hsk_user_update_lazy_body<V, NCH, FULL, GEN>(ua, bid);
     return;
   }
-  hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, bid - n_user_blocks);
+  if (LAZYI && bid < n_user_blocks + n_ahead_blocks) {
+    hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, bid - n_user_blocks);
+    return;
+  }
+  hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, bid - n_user_blocks - (LAZYI ? n_ahead_blocks : 0));
 }
 
 // small batches: whole-row item workgroups, interleaved with the ahead workgroups

@@ -44,4 +44,4 @@ for path in glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), rec
         for r in rows:
             r['Name'] = short(r['Name'])[:80]
             w.writerow(r)
-print(json.dumps({k: v for k, v in summary.items() if k.startswith(('k_fwd', 'k_item'))}, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k.startswith(('k_fwd', 'k_item', 'k_score', 'k_topk'))}, indent=1))
