@@ -69,6 +69,10 @@ SIGNATURES = {
     'hsk_rec_loss_grad': (c_int, [c_int32, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     'hsk_mf_backward': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                 c_int64, c_void_p] + [c_void_p] * 5 + [c_void_p, c_void_p]),
+    'hsk_embedding_gather': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'hsk_embedding_backward_ws_bytes': (c_int64, [c_int64, c_int64]),
+    'hsk_embedding_backward': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                       c_void_p, c_void_p]),
     'hsk_adamw_dense': (c_int, [c_void_p] * 4 + [c_int64] + [c_double] * 5 + [c_int64, c_void_p]),
     'hsk_opt_dense': (c_int, [c_int] + [c_void_p] * 4 + [c_int64] + [c_double] * 5 + [c_int64, c_void_p]),
     'hsk_sample_negatives_uniform': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,

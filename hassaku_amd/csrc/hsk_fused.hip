@@ -1115,3 +1115,152 @@ extern "C" int hsk_sample_negatives_uniform(const int64_t* csr_indptr, const int
 // multi-GPU phases (item table range-sharded, user table row-sharded)
 #include <algorithm>
 #include "hsk_shard.inc"
+
+// =============================================================================================
+// Generic embedding gather + its dense backward (the gather primitive the reference's other SGD models share:
+// nn.Embedding in ACF / UProtoMF / IProtoMF / UIProtoMF, algorithms/sgd_alg.py:187-570).  Forward: out[j] =
+// table[idx[j]].  Backward: grad_table[r] = sum of grad_out[j] over the positions j with idx[j] == r, added in
+// ascending j (the deterministic item sort of this file builds the row-major index), zero for rows nobody named --
+// what autograd's embedding_dense_backward returns, without atomics.
+// =============================================================================================
+template <int V, int NCH, bool FULL>
+__global__ __launch_bounds__(256) void k_rows_gather(const float* __restrict__ table, int n_rows, int D,
+                                                     const int64_t* __restrict__ idx, int n, float* __restrict__ out,
+                                                     int32_t* status) {
+  const int lane = hsk_lane();
+  const int j = blockIdx.x * 4 + hsk_uniform_i(threadIdx.x >> 6);
+  if (j >= n) return;
+  const int r = hsk_uniform_i(hsk_clamp_index(idx[j], n_rows, status));
+  hsk_row<V, NCH> row;
+  hsk_row_load<V, NCH, FULL>(row, table + (long long)r * D, lane, D);
+  hsk_row_store<V, NCH, FULL>(row, out + (long long)j * D, lane, D);
+}
+
+__global__ __launch_bounds__(256) void k_idx_to_i32(const int64_t* __restrict__ idx, int n, int n_rows,
+                                                    int* __restrict__ it32, int32_t* status) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) it32[j] = hsk_clamp_index(idx[j], n_rows, status);
+}
+
+template <int V, int NCH, bool FULL>
+__global__ __launch_bounds__(256) void k_rows_segment_sum(const float* __restrict__ grad_out, const int* __restrict__ perm,
+                                                          const int* __restrict__ offsets, int n_rows, int D,
+                                                          float* __restrict__ grad_table) {
+  const int lane = hsk_lane();
+  const int r = blockIdx.x * 4 + hsk_uniform_i(threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  using Row = hsk_row<V, NCH>;
+  const int beg = hsk_uniform_i(offsets[r]), end = hsk_uniform_i(offsets[r + 1]);
+  Row acc;
+  hsk_row_zero(acc);
+  for (int c0 = beg; c0 < end; c0 += 64) {
+    const int nr = min(64, end - c0);
+    const int mye = (lane < nr) ? perm[c0 + lane] : 0;
+    for (int j = 0; j < nr; j += 4) {
+      Row buf[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j + q < nr)
+          hsk_row_load<V, NCH, FULL>(buf[q], grad_out + (long long)hsk_readlane_i(mye, min(j + q, 63)) * D, lane, D);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j + q < nr) hsk_row_add(acc, buf[q]);
+    }
+  }
+  hsk_row_store<V, NCH, FULL>(acc, grad_table + (long long)r * D, lane, D);
+}
+
+extern "C" int hsk_embedding_gather(const float* table, int64_t n_rows, int64_t dim, const int64_t* idx, int64_t n,
+                                    float* out, int32_t* status, hsk_stream_t stream_) {
+  HSK_REQUIRE(table && idx && out, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_rows > 0 && n_rows < 0x7fffffff && dim > 0 && n >= 0 && n < 0x7fffffff, HSK_ERR_INVALID, "bad sizes");
+  if (n == 0) return HSK_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = hsk_dispatch_dim(dim, [&](auto v_, auto n_, auto f_) {
+    constexpr int V = decltype(v_)::value;
+    constexpr int NCH = decltype(n_)::value;
+    constexpr bool FULL = decltype(f_)::value;
+    k_rows_gather<V, NCH, FULL><<<(unsigned)hsk_ceil_div(n, 4), 256, 0, stream>>>(table, (int)n_rows, (int)dim, idx,
+                                                                                  (int)n, out, status);
+    return HSK_OK;
+  });
+  if (rc) return rc;
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+struct hsk_embw {   // scratch of hsk_embedding_backward
+  int* it32;
+  int2* perm1;
+  int *perm, *hist, *btot, *bstart, *offsets;
+  int64_t total;
+};
+
+static hsk_embw hsk_embw_carve(void* base, int64_t n_rows, int64_t n) {
+  hsk_embw w;
+  char* p = (char*)base;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += hsk_align_up(bytes, 256);
+    return r;
+  };
+  const int64_t hist_elems = hsk_sort_hist_elems(n_rows, std::max<int64_t>(n, 1));
+  w.it32 = (int*)take(n * 4);
+  w.perm1 = (int2*)take(n * 8);
+  w.perm = (int*)take(n * 4);
+  w.hist = (int*)take((hist_elems > 0 ? hist_elems : 4) * 4);
+  w.btot = (int*)take(HSK_SORT_MAX_BUCKETS * 4);
+  w.bstart = (int*)take((HSK_SORT_MAX_BUCKETS + 1) * 4);
+  w.offsets = (int*)take((n_rows + 1) * 4);
+  w.total = off;
+  return w;
+}
+
+extern "C" int64_t hsk_embedding_backward_ws_bytes(int64_t n_rows, int64_t n) {
+  if (n_rows <= 0 || n <= 0 || n >= 0x7fffffff || hsk_sort_hist_elems(n_rows, n) < 0) return -1;
+  return hsk_embw_carve(nullptr, n_rows, n).total;
+}
+
+extern "C" int hsk_embedding_backward(const float* grad_out, const int64_t* idx, int64_t n, int64_t n_rows, int64_t dim,
+                                      float* grad_table, void* ws, int64_t ws_bytes, int32_t* status,
+                                      hsk_stream_t stream_) {
+  HSK_REQUIRE(grad_out && idx && grad_table && ws, HSK_ERR_INVALID, "NULL pointer argument");
+  HSK_REQUIRE(n_rows > 0 && dim > 0 && n > 0, HSK_ERR_INVALID, "bad sizes");
+  const int64_t need = hsk_embedding_backward_ws_bytes(n_rows, n);
+  HSK_REQUIRE(need > 0, HSK_ERR_UNSUPPORTED, "table of %lld rows too large for the index sort", (long long)n_rows);
+  HSK_REQUIRE(ws_bytes >= need && ((uintptr_t)ws & 255) == 0, HSK_ERR_INVALID, "workspace: %lld bytes needed, %lld given",
+              (long long)need, (long long)ws_bytes);
+  hipStream_t stream = (hipStream_t)stream_;
+  const hsk_embw e = hsk_embw_carve(ws, n_rows, n);
+  k_idx_to_i32<<<(unsigned)hsk_ceil_div(n, 256), 256, 0, stream>>>(idx, (int)n, (int)n_rows, e.it32, status);
+  HSK_LAUNCH_CHECK();
+  // the item sort of the fused step, on a throw-away state that only says "n_rows keys, nothing lazy, no timing"
+  hsk_bprmf_state fake;
+  memset(&fake, 0, sizeof(fake));
+  fake.n_items = n_rows;
+  hsk_ws w;
+  memset(&w, 0, sizeof(w));
+  w.it32 = e.it32;
+  w.perm1 = e.perm1;
+  w.perm = e.perm;
+  w.hist = e.hist;
+  w.btot = e.btot;
+  w.bstart = e.bstart;
+  w.offsets = e.offsets;
+  hsk_bprmf_state* st = &fake;   // HSK_STAGE reads st->timing (NULL here)
+  (void)st;
+  int rc = hsk_launch_sort(&fake, w, n, stream);
+  if (rc) return rc;
+  rc = hsk_dispatch_dim(dim, [&](auto v_, auto n_, auto f_) {
+    constexpr int V = decltype(v_)::value;
+    constexpr int NCH = decltype(n_)::value;
+    constexpr bool FULL = decltype(f_)::value;
+    k_rows_segment_sum<V, NCH, FULL><<<(unsigned)hsk_ceil_div(n_rows, 4), 256, 0, stream>>>(
+        grad_out, e.perm, e.offsets, (int)n_rows, (int)dim, grad_table);
+    return HSK_OK;
+  });
+  if (rc) return rc;
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}

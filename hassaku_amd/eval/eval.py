@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from hassaku_amd import hip_ops
-from hassaku_amd.algorithms.base_classes import RecommenderAlgorithm
+from hassaku_amd.algorithms.base_classes import RecommenderAlgorithm, SGDBasedRecommenderAlgorithm
 from hassaku_amd.eval.metrics import ndcg_at_k_batch, precision_at_k_batch, recall_at_k_batch
 from hassaku_amd.utilities.utils import log_info_results
 
@@ -126,6 +126,22 @@ def evaluate_recommender_algorithm(alg: RecommenderAlgorithm, eval_loader, evalu
             wide = dataset.n_items >= hip_ops.FUSED_TOPK_MIN_ITEMS
             chunk = max(int(getattr(eval_loader, 'batch_size', 256) or 256), 16384 if wide else 4096)
             _hip_mf_eval(alg, dataset, evaluator, dev, chunk)
+    elif isinstance(alg, SGDBasedRecommenderAlgorithm) and hasattr(alg, 'lookup'):
+        # the other SGD models: item representations once, then every user batch against them (eval/eval.py:237-248);
+        # top-k and metrics on the device as for any dense score matrix
+        dev = next(alg.parameters()).device
+        excl = dataset.exclude_csr
+        with torch.no_grad():
+            i_repr = alg.get_item_representations(torch.arange(dataset.n_items, device=dev))
+            for u_idxs, _i_idxs, labels in eval_loader:
+                u_dev = u_idxs.to(dev)
+                out = alg.combine_user_item_representations(alg.get_user_representations(u_dev), i_repr).contiguous()
+                rows = np.repeat(np.arange(len(u_idxs)), excl.row_lengths()[u_idxs.cpu().numpy()])
+                cols = np.concatenate([excl.row(int(u)) for u in u_idxs]) if len(rows) else np.zeros(0, np.int64)
+                out[torch.as_tensor(rows, device=dev), torch.as_tensor(cols, dtype=torch.int64, device=dev)] = -torch.inf
+                evaluator.eval_batch(u_dev, out, labels.to(dev))
+            alg.get_and_reset_other_loss()
+            alg.check_indices()
     else:
         iterator = eval_loader
         if verbose:

@@ -186,6 +186,48 @@ def bias_backward(n_users, n_items, u_idx, i_idx, grad_logits, want_global_bias=
     return g_ib, g_ub, g_gb
 
 
+class _Embedding(torch.autograd.Function):
+    """rows = table[idx] through hsk_embedding_gather; backward = hsk_embedding_backward (dense gradient, duplicates
+    summed in ascending position -- nn.Embedding(sparse=False) semantics, deterministic)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, status):
+        _lib.require_gpu()
+        lib = _lib.load()
+        _chk(table, torch.float32, 'embedding table')
+        _chk(idx, torch.int64, 'embedding indices')
+        n_rows, dim = table.shape
+        flat = idx.reshape(-1)
+        out = torch.empty((flat.numel(), dim), dtype=torch.float32, device=table.device)
+        _lib.check(lib.hsk_embedding_gather(_p(table), n_rows, dim, _p(flat), flat.numel(), _p(out), _p(status),
+                                            _stream()), 'hsk_embedding_gather')
+        ctx.save_for_backward(flat)
+        ctx.shape, ctx.status = (n_rows, dim), status
+        return out.view(tuple(idx.shape) + (dim,))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        (flat,) = ctx.saved_tensors
+        n_rows, dim = ctx.shape
+        g = grad_out.reshape(-1, dim).contiguous()
+        grad_table = torch.empty((n_rows, dim), dtype=torch.float32, device=g.device)
+        if flat.numel() == 0:
+            return grad_table.zero_(), None, None
+        nbytes = lib.hsk_embedding_backward_ws_bytes(n_rows, flat.numel())
+        if nbytes <= 0:
+            raise ValueError('embedding table too large for the deterministic index sort')
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        _lib.check(lib.hsk_embedding_backward(_p(g), _p(flat), flat.numel(), n_rows, dim, _p(grad_table), _p(ws), nbytes,
+                                              _p(ctx.status), _stream()), 'hsk_embedding_backward')
+        return grad_table, None, None
+
+
+def embedding(table: torch.Tensor, idx: torch.Tensor, status=None) -> torch.Tensor:
+    """table[idx] -> idx.shape + (dim,), differentiable wrt `table` (dense gradient)."""
+    return _Embedding.apply(table, idx.contiguous(), status)
+
+
 def adamw_dense(p, g, m, v, lr, wd, step, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
     """In-place dense AdamW step (step is 1-based)."""
     _lib.require_gpu()

@@ -105,6 +105,18 @@ int hsk_mf_backward(const float* user_emb, const float* item_emb,
                     int32_t* status, hsk_stream_t stream);
 
 /*
+ * Embedding gather and its dense backward for the reference's other SGD models (nn.Embedding in ACF / UProtoMF /
+ * IProtoMF / UIProtoMF, algorithms/sgd_alg.py:187-570): out[j] = table[idx[j]];  grad_table[r] = sum of grad_out[j]
+ * over the positions with idx[j] == r, added in ascending j (deterministic, no atomics), zero for rows nobody named --
+ * what embedding_dense_backward returns for nn.Embedding(sparse=False).  ws: hsk_embedding_backward_ws_bytes(n_rows, n).
+ */
+int hsk_embedding_gather(const float* table, int64_t n_rows, int64_t dim, const int64_t* idx, int64_t n,
+                         float* out, int32_t* status, hsk_stream_t stream);
+int64_t hsk_embedding_backward_ws_bytes(int64_t n_rows, int64_t n);
+int hsk_embedding_backward(const float* grad_out, const int64_t* idx, int64_t n, int64_t n_rows, int64_t dim,
+                           float* grad_table, void* ws, int64_t ws_bytes, int32_t* status, hsk_stream_t stream);
+
+/*
  * One dense AdamW step on a flat parameter of n elements -- torch.optim.AdamW defaults
  * (train/trainer.py:52-53,147): p*=1-lr*wd; m=lerp(m,g,1-b1); v=b2*v+(1-b2)g^2;
  * p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  `step` is t (1-based, after increment).

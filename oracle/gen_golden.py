@@ -456,6 +456,61 @@ def gen_g9():
     print('g9 ok', sorted(k for k in fx if k.startswith('init.')))
 
 
+def gen_g10():
+    """G10: the anchor / prototype models (ACF, UProtoMF, IProtoMF, UIProtoMF -- SURVEY 8f rank 4): seeded
+    initialisation, logits of a batch, the extra losses, all parameter gradients of (bpr + reg_loss), parameters after
+    two AdamW steps, and the evaluation-form scores (every user against the whole item list)."""
+    from algorithms.sgd_alg import ACF, UProtoMF, IProtoMF, UIProtoMF
+    from train.rec_losses import RecBayesianPersonalizedRankingLoss
+    U, I, D, B, N, lr, wd = 30, 80, 24, 12, 5, 1e-3, 1e-4
+    builders = {
+        'acf': lambda: ACF(U, I, D, 6, 0.1, 0.01),
+        'uprotomf': lambda: UProtoMF(U, I, D, 7, 0.8, 0.6),
+        'iprotomf': lambda: IProtoMF(U, I, D, 7, 0.8, 0.6),
+        'uiprotomf': lambda: UIProtoMF(U, I, D, 5, 7, 0.8, 0.6, 0.7, 0.5),
+    }
+    for name, build in builders.items():
+        torch.manual_seed(64)
+        model = build()
+        fx = {'n_users': U, 'n_items': I, 'dim': D, 'lr': lr, 'wd': wd}
+        for k, v in state_np(model).items():
+            fx['init.' + k] = v
+        rng = np.random.RandomState(3)
+        loss_fn = RecBayesianPersonalizedRankingLoss()
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+        for step in (1, 2):
+            u = torch.from_numpy(rng.randint(0, U, size=B).astype(np.int64))
+            i = torch.from_numpy(rng.randint(0, I, size=(B, N + 1)).astype(np.int64))
+            labels = torch.zeros((B, N + 1), dtype=torch.float64)
+            labels[:, 0] = 1.
+            out = model(u, i)
+            rec = loss_fn.compute_loss(out, labels)
+            other = model.get_and_reset_other_loss()
+            total = rec + other['reg_loss']
+            fx[f's{step}.u_idx'], fx[f's{step}.i_idx'] = u.numpy(), i.numpy()
+            fx[f's{step}.logits'] = out.detach().numpy().copy()
+            fx[f's{step}.rec_loss'] = np.float64(rec.item())
+            for k, v in other.items():
+                fx[f's{step}.other.{k}'] = np.float64(float(v))
+            total.backward()
+            if step == 1:
+                for pname, p in model.named_parameters():
+                    fx['s1.grad.' + pname] = p.grad.numpy().copy()
+            opt.step()
+            opt.zero_grad()
+            for k, v in state_np(model).items():
+                fx[f's{step}.param.' + k] = v
+        with torch.no_grad():   # evaluation form, eval/eval.py:237-248
+            ue = torch.arange(0, 9)
+            scores = model.combine_user_item_representations(model.get_user_representations(ue),
+                                                             model.get_item_representations(torch.arange(I)))
+            model.get_and_reset_other_loss()
+        fx['eval.u'] = ue.numpy()
+        fx['eval.scores'] = scores.numpy().copy()
+        np.savez_compressed(os.path.join(OUT, f'g10_{name}.npz'), **fx)
+        print('g10', name, 'rec', fx['s1.rec_loss'], 'reg', fx['s1.other.reg_loss'])
+
+
 def gen_g7():
     from algorithms.algorithms_utils import AlgorithmsEnum
     from algorithms.sgd_alg import SGDMatrixFactorization
@@ -507,3 +562,4 @@ if __name__ == '__main__':
     gen_g7()
     gen_g8()
     gen_g9()
+    gen_g10()
