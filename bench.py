@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 ICACHE_GATHER_GBS = 8600.0   # same guide, "Indexed rows": uniformly random rows of an Infinity-Cache-resident table
 HBM_GATHER_GBS = 5750.0      # same guide: random 2.3 KB rows of a table far beyond the Infinity Cache, 5.7-5.8 TB/s
 MFMA_FP32_TFLOPS = 157.0     # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32; no xf32 on gfx950)
-PROFILE_DIR = {'ml10m': 'r2_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2_ml1m'}  # committed rocprofv3 summaries per workload
+PROFILE_DIR = {'ml10m': 'r2_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2_ml1m', 'ml100k': 'r2_ml100k'}  # committed rocprofv3 summaries
 LR, WD = 3e-4, 4e-5          # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
@@ -118,7 +118,8 @@ def build_sharded_state(data, D, B, N, device, comm, seed=64):
 # ------------------------------------------------------------------------------------------------
 # one training workload
 # ------------------------------------------------------------------------------------------------
-def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy_users='auto', all_stages=False):
+def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy_users='auto', all_stages=False,
+                 pure_gather=True):
     """-> dict(value, ms_per_step, fwd_us, fwd_launches, loss, B, N, D, data, csr, timing).  Timed exactly as the
     contract says: W warm-up steps, barrier + synchronize, K steps (+ the flush of lazily updated rows), barrier +
     synchronize; MAX over ranks."""
@@ -190,13 +191,25 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
         fence()
         st.disable_timing()
     timing = st.collect_timing()
+    pure_us = None
+    if comm is None and not replayed and st.st.lazy_users and pure_gather:
+        # the forward as a pure gather: the pending zero-gradient AdamW steps of the batch's user rows replayed by a
+        # stand-alone launch instead of inside the forward's registers (slower step, same results)
+        st.st.catchup_apart = 1
+        st.enable_timing(('fwd',), every=1)
+        run(32, warmup + steps)
+        fence()
+        st.disable_timing()
+        st.st.catchup_apart = 0
+        ms, cnt = st.collect_timing().get('fwd', (0.0, 0))
+        pure_us = ms * 1e3 / cnt if cnt else None
     st.check_status('timed region')
     loss = st.last_loss()
     assert np.isfinite(loss), loss
     fwd_ms, fwd_n = timing.get('fwd', (float('nan'), 0))
     out = dict(value=steps * B * N * world / elapsed, ms_per_step=elapsed * 1e3 / steps,
                fwd_us=(fwd_ms * 1e3 / fwd_n) if fwd_n else None, fwd_launches=int(fwd_n), loss=loss, B=B, N=N, D=D,
-               data=data, csr=csr, nnz=nnz, steps=steps, warmup=warmup, graph_replays=n_replays,
+               data=data, csr=csr, nnz=nnz, steps=steps, warmup=warmup, graph_replays=n_replays, pure_us=pure_us,
                lazy_users=bool(st.st.lazy_users) if comm is None else True)
     if all_stages:
         out['stage_us_per_step'] = {k: v[0] * 1e3 / max(v[1], 1) for k, v in timing.items()}
@@ -236,6 +249,13 @@ def roofline_of(workload, r):
            'item_table_MB': table_mb}
     if not cached:
         out['frac_of_measured_hbm_gather_5750'] = achieved / HBM_GATHER_GBS
+    if r.get('pure_us'):
+        # avg_us above includes the in-register replay of the user rows' pending AdamW steps (VALU work, ~9 us at the
+        # ml10m shape); with that replay in a launch of its own the kernel is the gather alone:
+        pa = by / (r['pure_us'] * 1e-6) / 1e9
+        out['pure_gather'] = {'avg_us': r['pure_us'], 'achieved': pa, 'frac': pa / out['peak'],
+                              'frac_of_hbm_spec_8000': pa / HBM_PEAK_GBS,
+                              'note': 'st.catchup_apart = 1, 32 eager steps after the timed region'}
     # the metric's own roofline: whole step against algorithmic gather bytes at the HBM spec peak
     out['step_frac_of_hbm_roofline'] = r['value'] / (HBM_PEAK_GBS * 1e9 / (by / (r['B'] * r['N'])))
     return out
@@ -395,6 +415,7 @@ def main():
     ap.add_argument('--lazy-users', action='store_true', help='lazy, exact user AdamW whatever the table size')
     ap.add_argument('--time-all-stages', action='store_true', help='event-time every stage (perturbs the step time)')
     ap.add_argument('--only', action='store_true', help='headline workload only: no extra workloads, no eval legs')
+    ap.add_argument('--no-pure-gather', action='store_true', help='skip the extra pure-gather timing pass (profiling: keeps the kernel averages of the timed region unmixed)')
     ap.add_argument('--eval-only', default=None, choices=sorted(EVAL_SHAPES), help='only the evaluation leg of this shape (profiling)')
     ap.add_argument('--sharded', action='store_true', help='N=1 through the multi-GPU code path (1-rank process group)')
     args = ap.parse_args()
@@ -439,7 +460,7 @@ def main():
         return
     r = run_training(args.workload, device, args.steps, args.warmup, comm=comm, prefetch=not args.no_prefetch,
                      lazy_users=False if args.dense_users else True if args.lazy_users else 'auto',
-                     all_stages=args.time_all_stages)
+                     all_stages=args.time_all_stages, pure_gather=not args.no_pure_gather)
     out = {
         'metric': 'BPR triplets/sec', 'value': r['value'], 'unit': 'triplets/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',

@@ -38,6 +38,7 @@ class HskBprmfState(ctypes.Structure):
         ('loss_kind', c_int32), ('opt_kind', c_int32), ('ssm_log_adjust', c_double),
         ('alias_prob', c_void_p), ('alias_idx', c_void_p),
         ('lazy_items', c_int32), ('graph_chunk', c_int32),
+        ('catchup_apart', c_int32), ('reserved3', c_int32),
         ('loss_out', c_void_p), ('status', c_void_p),
     ]
 

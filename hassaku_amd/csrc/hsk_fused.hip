@@ -674,7 +674,24 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     constexpr bool FULL = decltype(f_)::value;
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
     // lazy user AdamW: the forward replays the pending zero-gradient steps of its user row in registers and leaves
-    // the current row in ucur (no separate catch-up launch, no rewrite of the row before the owner's update)
+    // the current row in ucur (no separate catch-up launch, no rewrite of the row before the owner's update).
+    // st->catchup_apart: a stand-alone catch-up launch in front instead -- at B = 4096 the replay is ~9 us of pure VALU
+    // work at the head of every forward wave (forward 103 -> 112 us) but the extra launch costs more than it saves
+    // (224.5 vs 219.3 us per step), so it is off by default; with it the forward is the pure gather.
+    const bool apart = st->lazy_users && !capturing && st->catchup_apart != 0;
+    if (apart) {
+#define HSK_CATCH_UP(VV, GEN)                                                                                     \
+  HSK_STAGE(HSK_STAGE_USER, (k_user_catch_up<VV, GEN><<<(unsigned)B, 256, 0, stream>>>(                            \
+                                st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,      \
+                                st->v_user_bias, w.u32, w.owner, w.last_step, (int)B, D, (int)st->step, c,         \
+                                w.adam_tab, HSK_ADAM_TAB_LEN, nullptr, nullptr)))
+      if (D % 2 == 0) {
+        if (gen) HSK_CATCH_UP(2, true); else HSK_CATCH_UP(2, false);
+      } else {
+        if (gen) HSK_CATCH_UP(1, true); else HSK_CATCH_UP(1, false);
+      }
+#undef HSK_CATCH_UP
+    }
     // The forward kernel is launched through hipExtLaunchKernelGGL, whose start / stop events are the dispatch's own
     // timestamps: on a timed step they ARE the stage timing (kernel time as rocprofv3 reports it, no barrier packets
     // around the launch); otherwise the stop event is the prefetch's fork event.

@@ -281,6 +281,7 @@ class ShardedBprMf:
         st.workspace, st.workspace_bytes = _p(self.workspace), nbytes
         st.max_batch, st.max_cols = max_batch, max_cols
         st.lazy_users = 1
+        st.graph_chunk, st.catchup_apart = -1, 0
         if lazy_items == 'auto':   # worth it when most of the shard's rows are outside every batch
             lazy_items = D % 2 == 0 and I_loc >= 2 * cap and I_loc * D > hip_ops.LAZY_USERS_MIN_ELEMENTS
         st.lazy_items = 1 if lazy_items else 0

@@ -392,6 +392,7 @@ class BprMfFusedState:
         st.lazy_users = 1 if lazy_users else 0
         # steps_sampled() replays its steady-state loop as HIP graphs of this many steps (0: default 64, < 0: never)
         st.graph_chunk = int(graph_chunk)
+        st.catchup_apart = 0
         st.timing_mask = 0
         if loss not in LOSS_KINDS:
             raise ValueError(f'unknown loss {loss!r}')

@@ -229,6 +229,11 @@ typedef struct hsk_bprmf_state {
   /* hsk_bprmf_train_steps replays its steady-state loop as captured HIP graphs of this many steps (0: default 64,
      < 0: never, eager launches only); per-step scalars are read from a device descriptor, results are bit-identical */
   int32_t graph_chunk;
+  /* lazy_users: where the pending zero-gradient AdamW steps of the batch's user rows are replayed.  0 (default): inside
+     the forward kernel, in registers (fastest step); 1: by a stand-alone launch in front of it (the forward is then a
+     pure gather -- what bench.py times as `roofline.pure_gather`); results are bit-identical */
+  int32_t catchup_apart;
+  int32_t reserved3;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;
