@@ -51,13 +51,15 @@ class FullEvaluator:
         return sel
 
     def _accumulate(self, u_idxs: torch.Tensor, per_user: dict):
-        """per_user: metric name -> tensor [batch]"""
+        """per_user: metric name -> tensor [batch].  Sums and group sizes stay on the device (fp64): the host reads
+        them once, in get_results() -- not 12 x (1 + n_groups) times per batch."""
         for gi, rows in self._groups_of(u_idxs):
-            self.n_entries[gi] += int(u_idxs.shape[0] if rows is None else rows.sum().item())
+            n = u_idxs.shape[0] if rows is None else rows.sum()
+            self.n_entries[gi] = self.n_entries[gi] + n
             for name, vals in per_user.items():
                 v = vals if rows is None else vals[rows]
                 if self.aggr_by_group:
-                    self.group_metrics[gi][name] += v.sum().item()
+                    self.group_metrics[gi][name] = self.group_metrics[gi][name] + v.double().sum()
                 else:
                     self.group_metrics[gi][name] += [v.detach()]
 
@@ -86,7 +88,7 @@ class FullEvaluator:
             prefix = '' if gi == -1 else f'group_{gi}_'
             for name, acc in metrics.items():
                 if self.aggr_by_group:
-                    out[prefix + name] = acc / self.n_entries[gi]
+                    out[prefix + name] = float(acc) / float(self.n_entries[gi])
                 else:
                     out[prefix + name] = torch.cat(acc).cpu().numpy()
         self._reset_internal_dict()
