@@ -15,13 +15,39 @@
 #include "hsk_step_kernels.h"
 #include "hsk_item_sliced.h"
 #include "hsk_fwd_small.h"
+#include "hsk_fwd_part.h"
 #include <stdlib.h>
 
+#include <algorithm>
 #include <utility>
 #include <vector>
 
 #define HSK_ADAM_TAB_LEN 65536   // per-step (step_size, bc2_sqrt) table for the lazy replay
 #define HSK_FLUSH_EVERY 64       // lazy mode: dense catch-up sweep every this many steps (bounds the replay length)
+
+// =============================================================================================
+// item-partitioned forward (hsk_fwd_part.h): how many partitions for this table and batch
+// =============================================================================================
+// Pays when the item table is larger than an XCD's 4 MB L2 but a partition of it (mostly) fits, the batch fills the
+// chip, and a (positive, partition) unit still has a few rows to keep in flight.  Pure function of its arguments: the
+// sampler that buckets a batch's negatives and the step that trains on it must agree.  HSK_FWD_PARTS=1 turns it off,
+// =2/4/8 forces a partition count (where the shape allows partitions at all).
+#define HSK_PART_MAX 8
+static inline int64_t hsk_part_cols(int64_t n_cols, int n_part) { return n_cols + (n_part > 1 ? n_part - 1 : 0); }
+static int hsk_part_rule(int64_t n_items, int64_t dim, int64_t batch, int64_t n_neg, bool lazy_items) {
+  static const int env = getenv("HSK_FWD_PARTS") ? atoi(getenv("HSK_FWD_PARTS")) : 0;
+  if (env == 1 || lazy_items) return 1;
+  if (dim % 256 != 0 || dim > 2048 || batch < 2048 || n_neg > 256 || n_items < 64) return 1;
+  int P;
+  if (env == 2 || env == 4 || env == 8) {
+    P = env;
+  } else {
+    const double mb = (double)n_items * (double)dim * 4.0 / (1024.0 * 1024.0);
+    P = mb <= 4.5 ? 1 : mb <= 12.0 ? 2 : mb <= 24.0 ? 4 : mb <= 64.0 ? 8 : 1;
+  }
+  while (P > 1 && n_neg < 8 * P) P >>= 1;
+  return P;
+}
 
 // =============================================================================================
 // workspace carving
@@ -50,6 +76,10 @@ struct hsk_ws {
   int *stamp, *stamp_b;    // per buffer set: stamp[u] = step the set's batch is trained on (for its users)
   int* claim;              // ahead-of-time catch-up: last step at which a row was claimed
   int *touched, *n_touched, *touched_b, *n_touched_b;   // per buffer set: items with entries (compact), their count
+  // item-partitioned forward: dUb / loss_b hold n_part_max partial planes (part_stride floats apart); the batch rows
+  // have n_part - 1 extra columns
+  int n_part_max;
+  long long part_stride;
   // second set of the per-batch buffers: the next batch is sampled and sorted into it while this one trains
   int *u32_b, *it32_b, *perm_b, *hist_b, *btot_b, *bstart_b, *offsets_b, *owner_b, *cnt_b;
   int2* perm1_b;
@@ -86,7 +116,9 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
     off += hsk_align_up(bytes, 256);
     return r;
   };
-  const int64_t ent = max_batch * max_cols;
+  w.n_part_max = hsk_part_rule(n_items, dim, max_batch, std::min<int64_t>(max_cols - 1, 256), false);   // an upper bound
+  w.part_stride = max_batch * dim;
+  const int64_t ent = max_batch * (max_cols + w.n_part_max - 1);   // partitioned rows: the positive n_part times
   const int64_t hist_elems = hsk_sort_hist_elems(n_items, ent);
   w.u32 = (int*)take(max_batch * 4);
   w.it32 = (int*)take(ent * 4);
@@ -100,11 +132,11 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.owner = (int*)take(n_users * 4);
   w.cnt = (int*)take(n_users * 4);
   w.last_step = (int*)take(n_users * 4);
-  w.dUb = (float*)take(max_batch * dim * 4);
+  w.dUb = (float*)take(w.n_part_max * max_batch * dim * 4);
   w.ucur = (float*)take(max_batch * dim * 4);
   w.mcur = (float*)take(max_batch * dim * 4);
   w.vcur = (float*)take(max_batch * dim * 4);
-  w.loss_b = (double*)take(max_batch * 8);
+  w.loss_b = (double*)take(w.n_part_max * max_batch * 8);
   w.adam_tab = (float2*)take((HSK_ADAM_TAB_LEN + 1) * sizeof(float2));
   w.desc = (hsk_step_desc*)take(256);
   w.dupcnt = (int*)take(max_batch * 4);
@@ -134,7 +166,7 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
 extern "C" int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
                                              int64_t max_cols) {
   if (n_users <= 0 || n_items <= 0 || dim <= 0 || max_batch <= 0 || max_cols <= 1) return -1;
-  if (hsk_sort_hist_elems(n_items, max_batch * max_cols) < 0) return -1;
+  if (hsk_sort_hist_elems(n_items, max_batch * (max_cols + HSK_PART_MAX - 1)) < 0) return -1;
   return hsk_carve(nullptr, n_users, n_items, dim, max_batch, max_cols).total;
 }
 
@@ -423,7 +455,7 @@ template <int V, int NCH, bool FULL, int R, bool APPLY>
 static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, const float* Urows, const int* urow_index,
                                  int K, const hsk_adamw_consts& c, float* gI_out, float* gIb_out, hipStream_t stream,
                                  int64_t n_entries = 0, const hsk_user_lazy_args* ua = nullptr,
-                                 const hsk_ahead_args* aa = nullptr) {
+                                 const hsk_ahead_args* aa = nullptr, bool part = false) {
   const int I = (int)st->n_items, D = (int)st->dim;
   if (D % 2 != 0) {
     k_item_update<V, NCH, FULL, R, APPLY><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
@@ -439,7 +471,7 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
   const int n_sl = (int)hsk_ceil_div(D, 64 * vs);
   // merged launch at a small batch: whole-row item workgroups (n_slices_pad = 0 tells the kernel), see hsk_item_row_body
   static const int rows_on = getenv("HSK_ITEM_ROWS") ? atoi(getenv("HSK_ITEM_ROWS")) : 1;
-  const bool whole_rows = APPLY && ua && rows_on && n_entries <= 64 * 1024;
+  const bool whole_rows = APPLY && ua && rows_on && n_entries <= 64 * 1024 && !part;
   const int n_slices_pad = whole_rows ? 0 : (n_sl < 8 && 8 % n_sl == 0) ? n_sl : (int)hsk_align_up(n_sl, 8);
   const bool lazy = APPLY && st->lazy_items;
   // lazy item AdamW: only the items with entries (the sort's `touched` list; at most one per entry)
@@ -463,12 +495,17 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
     const int stride = n_ahead_oct ? item_oct / n_ahead_oct : 0;
     const int nab_big = ahead.coo_user ? (int)hsk_align_up(hsk_ceil_div(ahead.n, 4), 8) : 0;   // large-batch kernel
 
+    static const int user_last = getenv("HSK_USER_LAST") ? atoi(getenv("HSK_USER_LAST")) : 0;
 #define HSK_ITEM_USER(VS, GEN, LZ)                                                                             \
   do {                                                                                                         \
     if (whole_rows)                                                                                            \
       k_item_user_small<V, NCH, FULL, GEN, LZ><<<nblk + (unsigned)(nub + 8 * n_ahead_oct), 256, 0, stream>>>(    \
           ia, *ua, nub, dense, ahead, n_ahead_oct, stride);                                                    \
-    else                                                                                                       \
+    else if (part) {                                                                                           \
+      if constexpr (V == 4 && FULL && !LZ)                                                                      \
+        k_item_user<V, NCH, FULL, VS, GEN, LZ, true><<<nblk + (unsigned)nub, 256, 0, stream>>>(                   \
+            ia, *ua, nub, dense, ahead, user_last ? -(int)nblk : 0);                                            \
+    } else                                                                                                     \
       k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)(nub + (LZ ? nab_big : 0)), 256, 0, stream>>>(   \
           ia, *ua, nub, dense, ahead, LZ ? nab_big : 0);                                                       \
   } while (0)
@@ -495,12 +532,13 @@ static int hsk_launch_prep_sample(const hsk_bprmf_state* st, const hsk_ws& w, co
                                   int64_t batch, int64_t n_neg, uint64_t stream_id, hipStream_t stream) {
   const hsk_aux* ax = (const hsk_aux*)st->aux;
   const hsk_step_desc* desc = ax ? ax->g_desc : nullptr;
+  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0);
   // capture: `stream_id` arrives as the relative step of the batch being prepared
   HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
                                 st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
                                 st->csr_indices, (int)st->n_items, st->seed, stream_id, w.u32, w.it32, w.owner, w.cnt,
                                 st->status, 0, hsk_alias{st->alias_prob, st->alias_idx}, desc, desc ? (int)stream_id : 0,
-                                w.stamp));
+                                w.stamp, n_part));
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
@@ -611,7 +649,11 @@ static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set
   HSK_HIP(hipStreamWaitEvent(aux->side, aux->ev_fork, 0));
   int prc = hsk_launch_prep_sample(st, wn, aux->hint_order, aux->hint_start, aux->hint_batch, aux->hint_nneg,
                                    aux->g_desc ? (uint64_t)(aux->g_rel + 1) : (uint64_t)st->step, aux->side);
-  if (!prc) prc = hsk_launch_sort(st, wn, aux->hint_batch * (aux->hint_nneg + 1), aux->side);
+  if (!prc) {
+    const int64_t tot = aux->hint_batch * hsk_part_cols(aux->hint_nneg + 1, hsk_part_rule(st->n_items, st->dim, aux->hint_batch,
+                                                                                         aux->hint_nneg, st->lazy_items != 0));
+    prc = hsk_launch_sort(st, wn, tot, aux->side);
+  }
   if (prc) return prc;
   HSK_HIP(hipEventRecord(aux->ev_ready, aux->side));
   aux->pf_valid = true;
@@ -625,14 +667,17 @@ static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set
 }
 
 // stages after prep filled u32 / it32 / owner / cnt of `w` (and, with sorted == true, the item sort too)
+// n_part > 1: batch rows in the partitioned layout (the positive in n_part columns) -> item-partitioned forward
 static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool sorted, int64_t B, int64_t K,
-                        hipStream_t stream) {
+                        hipStream_t stream, int n_part = 1) {
   const hsk_ws w = hsk_select(w_all, set);
+  const int64_t K_real = K;
+  K = hsk_part_cols(K_real, n_part);   // columns of the batch rows: the positive n_part times (k_prep_sample)
   const int64_t total = B * K;
   const int U = (int)st->n_users, D = (int)st->dim;
   st->step += 1;
   const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step, st->opt_kind);
-  const double inv_bn_d = hsk_loss_norm(st->loss_kind, (double)B, (double)K);
+  const double inv_bn_d = hsk_loss_norm(st->loss_kind, (double)B, (double)K_real);
   const float inv_bn = (float)inv_bn_d;
   hsk_aux* aux = (hsk_aux*)st->aux;
   const bool gen = st->opt_kind != HSK_OPT_ADAMW;   // generic optimiser arithmetic instead of the AdamW-only kernels
@@ -722,6 +767,48 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
                           fwd_beg, fwd_end, 0, (const float*)st->user_emb, (const float*)st->item_emb,              \
                           (const float*)st->item_bias, (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D,    \
                           inv_bn, (float)st->ssm_log_adjust, w.g_s, w.dUb, w.loss_b, (const int*)nullptr, lz)
+    if (n_part > 1) {
+      // item-partitioned forward; the NEXT batch's user rows are brought up to date by leading workgroups of the same
+      // launch (pure VALU work beside a kernel that waits on the L2 / the fabric), see hsk_fwd_part.h
+      if constexpr (V == 4 && FULL) {
+        hsk_ahead_args aa = {};
+        int n_ahead = 0;
+        static const int ahead_on = getenv("HSK_AHEAD") ? atoi(getenv("HSK_AHEAD")) : 1;
+        if (st->lazy_users && aux && ahead_on && !apart && (aux->pf_valid || aux->hint_valid)) {
+          const bool pf = aux->pf_valid;
+          aa = hsk_ahead_args{st->coo_user, pf ? aux->pf_order : aux->hint_order, pf ? aux->pf_start : aux->hint_start,
+                              (int)(pf ? aux->pf_batch : aux->hint_batch), w.stamp, w.claim, st->user_emb, st->m_user_emb,
+                              st->v_user_emb, st->user_bias, st->m_user_bias, st->v_user_bias, w.last_step, D,
+                              (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN, gdesc, grel};
+          n_ahead = (int)hsk_align_up(hsk_ceil_div(aa.n, 4), 8);
+        }
+        const unsigned n_unit = 8u * (unsigned)hsk_ceil_div(hsk_ceil_div(B, 4), 8 / n_part);
+        static const int ahead_last = getenv("HSK_AHEAD_LAST") ? atoi(getenv("HSK_AHEAD_LAST")) : 0;
+        const hsk_part_args pa = {n_part, (int)st->n_items, w.part_stride, n_ahead, ahead_last ? (int)n_unit : 0};
+        const unsigned grid = (unsigned)n_ahead + n_unit;
+#define HSK_LAUNCH_FWD_PART(LK, GEN)                                                                                 \
+  if (capturing)                                                                                                    \
+    hipLaunchKernelGGL((k_fwd_part<V, NCH, FULL, R, LK, GEN>), dim3(grid), dim3(256), 0, stream,                     \
+                       (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,         \
+                       (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b, lz,  \
+                       pa, aa);                                                                                     \
+  else                                                                                                              \
+    hipExtLaunchKernelGGL((k_fwd_part<V, NCH, FULL, R, LK, GEN>), dim3(grid), dim3(256), 0, stream, fwd_beg, fwd_end,  \
+                          0, (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,   \
+                          (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b,  \
+                          lz, pa, aa)
+        if (st->loss_kind == HSK_LOSS_BCE) {
+          if (gen) { HSK_LAUNCH_FWD_PART(HSK_LOSS_BCE, true); } else { HSK_LAUNCH_FWD_PART(HSK_LOSS_BCE, false); }
+        } else {
+          if (gen) { HSK_LAUNCH_FWD_PART(HSK_LOSS_BPR, true); } else { HSK_LAUNCH_FWD_PART(HSK_LOSS_BPR, false); }
+        }
+#undef HSK_LAUNCH_FWD_PART
+        return HSK_OK;
+      } else {
+        hsk_set_error("internal: item-partitioned forward selected for dim %d", D);
+        return HSK_ERR_UNSUPPORTED;
+      }
+    }
     // small batches: a workgroup per positive (hsk_fwd_small.h); the one-wave kernel would leave most SIMDs idle
     // and walk each positive's rows as a chain of memory latencies
 #define HSK_LAUNCH_FWD_WG(LK, NW)                                                                                   \
@@ -768,14 +855,14 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     constexpr int R = (V * NCH >= 16) ? 2 : 4;
     // user update: the owners' rows (lazy: pending steps were replayed by the forward) or a dense sweep over the
     // table; + one workgroup for the loss reduction / global bias.  Even D: in the item pass's own launch.
-    const hsk_finish_args fin = {w.loss_b, (int)B, inv_bn_d, st->loss_out, st->global_bias, st->m_global_bias,
-                                 st->v_global_bias};
+    const hsk_finish_args fin = {w.loss_b, (int)(B * n_part), inv_bn_d, st->loss_out, st->global_bias,
+                                 st->m_global_bias, st->v_global_bias};   // partitioned forward: [n_part, B] partial terms
     const bool lazy = st->lazy_users != 0;
     const hsk_user_lazy_args ua = {st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias,
                                    st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,
                                    (int)st->step, c, fin, w.dupcnt, w.duplist, lazy ? w.adam_tab : nullptr,
                                    HSK_ADAM_TAB_LEN, w.ucur, w.mcur, w.vcur, lazy ? 0 : U, gdesc, grel, w.adam_tab,
-                                   HSK_ADAM_TAB_LEN};
+                                   HSK_ADAM_TAB_LEN, n_part, w.part_stride};
     const bool timed_apart = st->timing && st->timing_now &&
                              (((st->timing_mask >> HSK_STAGE_ITEM) | (st->timing_mask >> HSK_STAGE_USER)) & 1);
     if (D % 2 == 0 && !timed_apart) {
@@ -798,13 +885,24 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       }
       // the item pass reads the user rows from ucur, the user blocks rewrite the table: independent -> one launch
       hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, w.ucur, nullptr, (int)K, c, nullptr, nullptr, stream, total, &ua,
-                                                  &aa);
+                                                  &aa, n_part > 1);
     } else {
       const bool from_ucur = lazy || D % 2 == 0;
       HSK_STAGE(HSK_STAGE_ITEM, (hsk_launch_item_pass<V, NCH, FULL, R, true>(
                                     st, w, from_ucur ? w.ucur : st->user_emb, from_ucur ? nullptr : w.u32, (int)K, c,
                                     nullptr, nullptr, stream, total, nullptr)));
-      if (lazy) {
+      if (n_part > 1) {   // partial gradient rows: the PART flavours (V == 4 && FULL by the partition rule)
+        if constexpr (V == 4 && FULL) {
+          const unsigned gl = (unsigned)hsk_ceil_div(B, 4) + 1, gd = (unsigned)hsk_ceil_div(U, 4) + 1;
+          if (lazy) {
+            if (gen) HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, true, true><<<gl, 256, 0, stream>>>(ua)));
+            else     HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, false, true><<<gl, 256, 0, stream>>>(ua)));
+          } else {
+            if (gen) HSK_STAGE(HSK_STAGE_USER, (k_user_update_dense<V, NCH, FULL, true, true><<<gd, 256, 0, stream>>>(ua)));
+            else     HSK_STAGE(HSK_STAGE_USER, (k_user_update_dense<V, NCH, FULL, false, true><<<gd, 256, 0, stream>>>(ua)));
+          }
+        }
+      } else if (lazy) {
         if (gen)
           HSK_STAGE(HSK_STAGE_USER, (k_user_update_lazy<V, NCH, FULL, true><<<(unsigned)hsk_ceil_div(B, 4) + 1, 256, 0, stream>>>(ua)));
         else
@@ -849,11 +947,12 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
   const int set = st->aux ? (((hsk_aux*)st->aux)->cur_set ^ 1) : 0;
   const hsk_ws ws = hsk_select(w, set);
+  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0);
   HSK_STAGE(HSK_STAGE_PREP, k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
                                 u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, ws.u32,
-                                ws.it32, ws.owner, ws.cnt, st->status, ws.stamp, (int)st->step + 1));
+                                ws.it32, ws.owner, ws.cnt, st->status, ws.stamp, (int)st->step + 1, n_part));
   HSK_LAUNCH_CHECK();
-  return hsk_run_step(st, w, set, false, batch, n_cols, stream);
+  return hsk_run_step(st, w, set, false, batch, n_cols, stream, n_part);
 }
 
 extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
@@ -870,18 +969,19 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   // the RNG stream id is the index of the step about to be taken: every step draws fresh negatives
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
   hsk_aux* aux = (hsk_aux*)st->aux;
+  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0);
   if (aux && aux->pf_valid && aux->pf_order == order && aux->pf_start == start && aux->pf_batch == batch &&
       aux->pf_nneg == n_neg && aux->pf_step == st->step) {
     // this batch was sampled and sorted on the side stream during the previous step
     aux->pf_valid = false;
     HSK_HIP(hipStreamWaitEvent(stream, aux->ev_ready, 0));
-    return hsk_run_step(st, w, aux->cur_set ^ 1, true, batch, n_neg + 1, stream);
+    return hsk_run_step(st, w, aux->cur_set ^ 1, true, batch, n_neg + 1, stream, n_part);
   }
   if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
   const int set = aux ? (aux->cur_set ^ 1) : 0;
   if ((rc = hsk_launch_prep_sample(st, hsk_select(w, set), order, start, batch, n_neg, (uint64_t)st->step, stream)))
     return rc;
-  return hsk_run_step(st, w, set, false, batch, n_neg + 1, stream);
+  return hsk_run_step(st, w, set, false, batch, n_neg + 1, stream, n_part);
 }
 
 // =============================================================================================
@@ -963,7 +1063,9 @@ static int hsk_capture_steps(hsk_bprmf_state* st, const hsk_ws& w, int64_t n, in
       aux->hint_batch = batch;
       aux->hint_nneg = n_neg;
     }
-    if (rc == HSK_OK) rc = hsk_run_step(st, w, set, sorted, batch, K, stream);
+    if (rc == HSK_OK)
+      rc = hsk_run_step(st, w, set, sorted, batch, K, stream,
+                        hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0));
     set ^= 1;
   }
   const hipError_t e = hipStreamEndCapture(stream, &graph);
@@ -1075,18 +1177,25 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   const int64_t total = batch * n_cols;
   if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set);
+  // partitioned row layout: the positive sits in n_part columns, the caller sees it once
+  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0);
   k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
-                                                                                      u_out, i_out);
+                                                                                      u_out, i_out, (int)n_cols, n_part);
   HSK_LAUNCH_CHECK();
   return HSK_OK;
+}
+
+extern "C" int64_t hsk_bprmf_batch_columns(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols) {
+  if (!st || batch <= 0 || n_cols < 2) return -1;
+  return hsk_part_cols(n_cols, hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0));
 }
 
 extern "C" int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries, int32_t* perm_out, int32_t* offsets_out,
                                    hsk_stream_t stream_) {
   int rc = hsk_check_state(st);
   if (rc) return rc;
-  HSK_REQUIRE(perm_out && offsets_out && n_entries > 0 && n_entries <= st->max_batch * st->max_cols, HSK_ERR_INVALID,
-              "bad argument");
+  HSK_REQUIRE(perm_out && offsets_out && n_entries > 0 && n_entries <= st->max_batch * (st->max_cols + HSK_PART_MAX - 1),
+              HSK_ERR_INVALID, "bad argument");
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set);
   HSK_HIP(hipMemcpyAsync(perm_out, w.perm, n_entries * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream_));

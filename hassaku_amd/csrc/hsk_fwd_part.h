@@ -1,0 +1,157 @@
+// hsk_fwd_part.h -- the forward of the fused step with the item table cut into P range partitions, one partition per
+// group of 8/P XCDs.
+//
+// k_fwd_ugrad gathers uniformly random rows of the whole item table on every XCD: a 4 MB L2 holds 18 % of a 21.9 MB
+// table, the rest of the 850 MB per step comes over the fabric from the Infinity Cache (8.3 TB/s, 104 us).  Here a wave
+// owns (positive b, partition q): it weighs only the negatives of b whose item lies in partition q, and the workgroups
+// of partition q all run on the same 8/P XCDs (workgroup index mod 8 -> XCD, the observed round-robin dispatch: a speed
+// assumption only), so an XCD's L2 only ever sees I/P item rows -- at P = 4 and the ml10m shape 5.5 MB, three quarters
+// of it resident.  Measured stand-alone (profiles/probes/part_fwd.hip, us): P = 1 106 | 2 89 | 4 72 | 8 78.
+//
+// Nothing is exchanged inside the launch.  Every unit loads the user row and the positive's item row itself (s_0 is
+// recomputed by each of the P units from the same bytes in the same order: identical bits), picks ITS negatives out of
+// the positive's row of ids (one ballot per 64 columns, a list in LDS), weighs them and leaves PARTIAL results: a
+// partial user-row gradient dUp[q][b] (its share of the positive's term included: -gsum_q * I[i_0]), its share -gsum_q
+// of d loss/d s_0, and a partial loss term.  The batch rows have K + P - 1 columns: the positive item P times
+// (k_prep_sample), then the negatives; unit q leaves its share of d loss/d s_0 in column q, so the item pass --
+// unchanged -- meets P entries of the positive item whose weights add up to d loss/d s_0.  The owner's user update
+// adds the P partial rows (hsk_user_row_chunks<PART>).
+//
+// Lazy user rows: the ahead-of-time catch-up (hsk_user_ahead_body, workgroups of this launch for the NEXT batch) keeps
+// the rows current; a row that is behind all the same (no hint, first step) is replayed in registers by each of its P
+// units, unit 0 publishes it -- correct, just P times the arithmetic for that row.
+#pragma once
+#include "hsk_step_kernels.h"
+
+struct hsk_part_args {
+  int n_part;                    // P: 2, 4 or 8; partition q = items [ceil(q I / P), ceil((q + 1) I / P))
+  int n_items;
+  long long part_stride;         // floats between the partial planes of dUp
+  int n_ahead_blocks;            // workgroups that run hsk_user_ahead_body (a multiple of 8)
+  int n_unit_blocks;             // > 0: the ahead workgroups FOLLOW this many unit workgroups; 0: they lead
+};
+#define HSK_PART_LIST_MAX 256    // negatives per positive (the partition rule keeps n_neg <= 256)
+
+template <int V, int NCH, bool FULL, int R, int LOSS, bool GEN>
+__global__ __launch_bounds__(256) void k_fwd_part(const float* __restrict__ Uw, const float* __restrict__ Iw,
+                                                  const float* __restrict__ Ib, const int* __restrict__ u32,
+                                                  const int* __restrict__ it32, int B, int K /* columns */, int D, float inv_norm,
+                                                  float* __restrict__ g_s, float* __restrict__ dUp,
+                                                  double* __restrict__ loss_p, hsk_lazy_user_args lz, hsk_part_args pa,
+                                                  hsk_ahead_args aa) {
+  static_assert(LOSS == HSK_LOSS_BPR || LOSS == HSK_LOSS_BCE, "the sampled softmax needs all negatives in one wave");
+  int bid = (int)blockIdx.x;
+  if (pa.n_unit_blocks > 0) {
+    if (bid >= pa.n_unit_blocks) {
+      hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, bid - pa.n_unit_blocks);
+      return;
+    }
+  } else {
+    if (bid < pa.n_ahead_blocks) {
+      hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, bid);
+      return;
+    }
+    bid -= pa.n_ahead_blocks;
+  }
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int P = pa.n_part, M = 8 / P;
+  const int xcd = bid & 7, q = xcd / M, sx = xcd - q * M, t = bid >> 3;
+  const int b = (t * M + sx) * 4 + wave;
+  if (b >= B) return;
+
+  using Row = hsk_row<V, NCH>;
+  const int* __restrict__ irow = it32 + (long long)b * K;
+  const int u = hsk_uniform_i(u32[b]);
+  const int i0 = hsk_uniform_i(irow[0]);
+  // this unit's negatives: (item id, column) of the ids in [lo, hi), in column order
+  __shared__ int lst_id[4][HSK_PART_LIST_MAX], lst_col[4][HSK_PART_LIST_MAX];
+  const int lo = (int)(((long long)q * pa.n_items + P - 1) / P), hi = (int)(((long long)(q + 1) * pa.n_items + P - 1) / P);
+  int n_mine = 0;
+  for (int c0 = P; c0 < K; c0 += 64) {
+    const int c = c0 + lane;
+    const int id = (c < K) ? irow[c] : -1;
+    const bool mine = id >= lo && id < hi;
+    const unsigned long long m = __ballot(mine);
+    if (mine) {
+      const int pos = n_mine + __popcll(m & ((1ull << lane) - 1ull));
+      lst_id[wave][pos] = id;
+      lst_col[wave][pos] = c;
+    }
+    n_mine += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int beg = 0, end = n_mine;
+
+  Row ur, r0, acc;
+  hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
+  hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  if (lz.mU)
+    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, q == 0);
+  else if (lz.ucur && q == 0)
+    hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
+  hsk_row_zero(acc);
+  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
+
+  float gsum = 0.f;
+  double lsum = 0.0;
+  for (int kc = beg; kc < end; kc += 64) {
+    const int nr = min(64, end - kc);
+    const int myidx = (lane < nr) ? lst_id[wave][kc + lane] : i0;
+    const int mycol = (lane < nr) ? lst_col[wave][kc + lane] : 0;
+    const float mybias = Ib ? Ib[myidx] : 0.f;
+    float gv = 0.f, xv = 0.f;
+    Row bufA[R], bufB[R];
+    auto prefetch = [&](Row(&buf)[R], int j) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (j + r < nr)
+          hsk_row_load<V, NCH, FULL>(buf[r], Iw + (long long)hsk_readlane_i(myidx, j + r) * D, lane, D);
+    };
+    auto process = [&](Row(&buf)[R], int j) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (j + r < nr) {
+          const float s = hsk_wave_sum(hsk_row_dot_partial(ur, buf[r])) + hsk_readlane_f(mybias, j + r);
+          float g, x;
+          if (LOSS == HSK_LOSS_BPR) {
+            x = s0 - s;
+            g = inv_norm / (1.f + expf(x));    // sigma(-x)/(B*N) = d loss / d s_neg
+            gsum += g;
+          } else {
+            x = s;
+            g = inv_norm / (1.f + expf(-s));   // sigma(s)/(B*K), label 0
+          }
+          hsk_row_axpy(acc, g, buf[r]);
+          gv = (lane == j + r) ? g : gv;
+          xv = (lane == j + r) ? x : xv;
+        }
+      }
+    };
+    prefetch(bufA, 0);
+    for (int j = 0; j < nr; j += 2 * R) {
+      prefetch(bufB, j + R);
+      process(bufA, j);
+      prefetch(bufA, j + 2 * R);
+      process(bufB, j + R);
+    }
+    if (lane < nr) {
+      g_s[(long long)b * K + mycol] = gv;
+      lsum += (double)hsk_softplus(LOSS == HSK_LOSS_BPR ? -xv : xv);
+    }
+  }
+  float gp;   // this unit's share of -d loss/d s_0
+  if (LOSS == HSK_LOSS_BPR) {
+    gp = gsum;
+  } else {
+    gp = (q == 0) ? inv_norm / (1.f + expf(s0)) : 0.f;   // -(sigma(s_0) - 1)/(B*K), once per positive
+    if (q == 0 && lane == 0) lsum += (double)hsk_softplus(-s0);
+  }
+  hsk_row_axpy(acc, -gp, r0);
+  hsk_row_store<V, NCH, FULL>(acc, dUp + (long long)q * pa.part_stride + (long long)b * D, lane, D);
+  const double l = hsk_wave_sum_f64(lsum);
+  if (lane == 0) {
+    g_s[(long long)b * K + q] = -gp;
+    loss_p[(long long)q * B + b] = l;
+  }
+}

@@ -250,16 +250,26 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
 // waves per SIMD allow -- hence the explicit occupancy request on the large-batch kernel.
 // LAZYI (huge catalogues, lazy item AdamW): the launch is AdamW traffic on the touched item rows with the VALUs idle,
 // so n_ahead_blocks workgroups of hsk_user_ahead_body ride in front of the item workgroups here too.
-template <int V, int NCH, bool FULL, int VS, bool GEN, bool LAZYI>
+// PART: the gradient rows are sums of partial rows (item-partitioned forward, hsk_fwd_part.h); a separate instantiation,
+// so that the default kernel's register allocation (scalar spills in particular) stays what it was.
+template <int V, int NCH, bool FULL, int VS, bool GEN, bool LAZYI, bool PART = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int dense_users, hsk_ahead_args aa,
                  int n_ahead_blocks) {
-  const int bid = (int)blockIdx.x;
+  int bid = (int)blockIdx.x;
+  if (PART && n_ahead_blocks < 0) {   // PART: -n_ahead_blocks item workgroups first, the user workgroups behind them
+    if (bid < -n_ahead_blocks) {
+      hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, bid);
+      return;
+    }
+    bid -= -n_ahead_blocks;
+    n_ahead_blocks = 0;
+  }
   if (bid < n_user_blocks) {
     if (dense_users)
-      hsk_user_update_dense_body<V, NCH, FULL, GEN>(ua, bid);
+      hsk_user_update_dense_body<V, NCH, FULL, GEN, PART>(ua, bid);
     else
-      hsk_user_update_lazy_body<V, NCH, FULL, GEN>(ua, bid);
+      hsk_user_update_lazy_body<V, NCH, FULL, GEN, PART>(ua, bid);
     return;
   }
   if (LAZYI && bid < n_user_blocks + n_ahead_blocks) {

@@ -12,12 +12,23 @@ __global__ __launch_bounds__(256) void k_prep_external(const int64_t* __restrict
                                                        int* __restrict__ it32,
                                                        int* __restrict__ owner, int* __restrict__ cnt,
                                                        int32_t* status, int* __restrict__ stamp = nullptr,
-                                                       int stamp_val = 0) {
+                                                       int stamp_val = 0, int n_part = 1) {
+  // n_part > 1 (item-partitioned forward, hsk_fwd_part.h): rows of K + n_part - 1 columns, the positive item in the
+  // first n_part of them (unit q of the forward leaves its share of d loss/d s_0 in column q)
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * K;
   if (e < total) {
     const int it = hsk_clamp_index(i_idx[e], n_items, status);
-    it32[e] = it;
+    if (n_part > 1) {
+      const long long b = e / K, k = e - b * K;
+      int* row = it32 + b * (K + n_part - 1);
+      if (k == 0)
+        for (int q = 0; q < n_part; ++q) row[q] = it;
+      else
+        row[k + n_part - 1] = it;
+    } else {
+      it32[e] = it;
+    }
   }
   if (e < B) {
     const int u = hsk_clamp_index(u_idx[e], n_users, status);
@@ -109,7 +120,8 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
                                                      int32_t* status, int b_offset = 0,
                                                      hsk_alias at = hsk_alias{nullptr, nullptr},
                                                      const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0,
-                                                     int* __restrict__ stamp = nullptr) {
+                                                     int* __restrict__ stamp = nullptr, int n_part = 1) {
+  // n_part > 1: rows of K + n_part - 1 columns, the positive item in the first n_part (see k_prep_external)
   // stamp (optional): stamp[u] = the (1-based) step this batch is trained on, for every user of the batch -- how a
   // kernel of that step tells the rows being updated from the rows it may bring up to date ahead of time
   // b_offset: offset added to the batch position in the RNG counter (a slice of a larger global batch).
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
   const int ipos = coo_item[pos];
   const long long lo = csr_indptr[u], hi = csr_indptr[u + 1];
   const int K = n_neg + 1;
-  int* row = it32 + (long long)b * K;
+  int* row = it32 + (long long)b * (K + n_part - 1);
   // stage the user's sorted positives in LDS: the rejection test is a ~7-step binary search per draw, and as
   // dependent global loads that chain (not the RNG) is what the sampler spends its time on
   __shared__ int32_t lds_row[4][HSK_SAMPLER_LDS_ROW];
@@ -142,10 +154,10 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
   for (int n = lane; n < n_neg; n += 64) {
     const int neg = hsk_draw_negative(set, 0, len, (uint32_t)n_items, (uint32_t)(b + b_offset), (uint32_t)n, seed,
                                       stream_id, status, at);
-    row[1 + n] = neg;
+    row[n_part + n] = neg;
   }
+  if (lane < n_part) row[lane] = ipos;
   if (lane == 0) {
-    row[0] = ipos;
     u32[b] = u;
     if (owner) {
       atomicMin(&owner[u], b);

@@ -616,7 +616,27 @@ struct hsk_user_lazy_args {
   int n_users;            // dense sweep (hsk_user_update_dense_body): rows of the table
   const hsk_step_desc* desc; int rel;   // graph replay: step = desc->step0 + rel + 1, c from ctab
   const float2* ctab; int ctab_len;
+  int n_part; long long part_stride;   // item-partitioned forward: a gradient row is the sum of n_part partial rows,
+                                       // part_stride floats apart (n_part <= 1: one row)
 };
+
+// gradient chunk of batch position b: the partial rows added in partition order
+template <int V>
+__device__ __forceinline__ hsk_vec<V> hsk_grad_chunk(const hsk_user_lazy_args& a, int b, int off) {
+  const float* src = a.dUb + (long long)b * a.D + off;
+  hsk_vec<V> g = hsk_ldg<V>(src);
+  for (int q0 = 1; q0 < a.n_part; q0 += 3) {   // three loads in flight, then their sum in partition order
+    hsk_vec<V> t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      t[j] = (q0 + j < a.n_part) ? hsk_ldg<V>(src + (long long)(q0 + j) * a.part_stride) : hsk_zero<V>();
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < V; ++i) g.v[i] += t[j].v[i];
+  }
+  return g;
+}
 
 // step index and optimiser scalars of this launch: the immediate ones, or (graph replay) derived on the device
 __device__ __forceinline__ void hsk_resolve_step(const hsk_step_desc* desc, int rel, const float2* ctab, int ctab_len,
@@ -631,7 +651,7 @@ __device__ __forceinline__ void hsk_resolve_step(const hsk_step_desc* desc, int 
 // workgroups that share the launch their occupancy).  Gradient = dUb[b] + the rows of the user's further entries in
 // the batch (n entries in all), added in ascending b: usually those registered with the owner (dupcnt / duplist, in
 // arrival order: ranked here), otherwise the batch is scanned.  n == 0: no gradient (dense sweep over an idle row).
-template <int V, int NCH, bool FULL, bool GEN>
+template <int V, int NCH, bool FULL, bool GEN, bool PART = false>
 __device__ __forceinline__ void hsk_user_row_chunks(const hsk_user_lazy_args& a, int row, int b, int n,
                                                     const float* __restrict__ psrc, const float* __restrict__ msrc,
                                                     const float* __restrict__ vsrc, float* __restrict__ prow,
@@ -669,12 +689,12 @@ __device__ __forceinline__ void hsk_user_row_chunks(const hsk_user_lazy_args& a,
       p = hsk_ldg<V>(psrc + off);
       m = hsk_ldg<V>(msrc + off);
       v = hsk_ldg<V>(vsrc + off);
-      if (n > 0) g = hsk_ldg<V>(a.dUb + (long long)b * D + off);
+      if (n > 0) g = PART ? hsk_grad_chunk<V>(a, b, off) : hsk_ldg<V>(a.dUb + (long long)b * D + off);
     }
 #pragma unroll
     for (int r = 0; r < HSK_DUP_MAX; ++r)
       if (r < nd_list && live) {
-        const hsk_vec<V> t = hsk_ldg<V>(a.dUb + (long long)dl[r] * D + off);
+        const hsk_vec<V> t = PART ? hsk_grad_chunk<V>(a, dl[r], off) : hsk_ldg<V>(a.dUb + (long long)dl[r] * D + off);
 #pragma unroll
         for (int q = 0; q < V; ++q) g.v[q] += t.v[q];
       }
@@ -687,7 +707,7 @@ __device__ __forceinline__ void hsk_user_row_chunks(const hsk_user_lazy_args& a,
           const int j = __builtin_ctzll(mask);
           mask &= mask - 1;
           if (live) {
-            const hsk_vec<V> t = hsk_ldg<V>(a.dUb + (long long)(g0 + j) * D + off);
+            const hsk_vec<V> t = PART ? hsk_grad_chunk<V>(a, g0 + j, off) : hsk_ldg<V>(a.dUb + (long long)(g0 + j) * D + off);
 #pragma unroll
             for (int q = 0; q < V; ++q) g.v[q] += t.v[q];
           }
@@ -705,7 +725,7 @@ __device__ __forceinline__ void hsk_user_row_chunks(const hsk_user_lazy_args& a,
   }
 }
 
-template <int V, int NCH, bool FULL, bool GEN>
+template <int V, int NCH, bool FULL, bool GEN, bool PART = false>
 __device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_args& a0, int bid) {
   hsk_user_lazy_args a = a0;
   hsk_resolve_step(a.desc, a.rel, a.ctab, a.ctab_len, a.step, a.c);
@@ -733,7 +753,7 @@ __device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_ar
   const float* psrc = behind ? a.ucur + (long long)b * D : prow;
   const float* msrc = behind ? a.mcur + (long long)b * D : mrow;
   const float* vsrc = behind ? a.vcur + (long long)b * D : vrow;
-  hsk_user_row_chunks<V, NCH, FULL, GEN>(a, row, b, n, psrc, msrc, vsrc, prow, mrow, vrow, lane);
+  hsk_user_row_chunks<V, NCH, FULL, GEN, PART>(a, row, b, n, psrc, msrc, vsrc, prow, mrow, vrow, lane);
   if (lane == 0) {
     if (a.Ub) {
       float pb = a.Ub[row], mb = a.mUb[row], vb = a.vUb[row];
@@ -751,15 +771,15 @@ __device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_ar
   }
 }
 
-template <int V, int NCH, bool FULL, bool GEN>
+template <int V, int NCH, bool FULL, bool GEN, bool PART = false>
 __global__ __launch_bounds__(256) void k_user_update_lazy(hsk_user_lazy_args a) {
-  hsk_user_update_lazy_body<V, NCH, FULL, GEN>(a, (int)blockIdx.x);
+  hsk_user_update_lazy_body<V, NCH, FULL, GEN, PART>(a, (int)blockIdx.x);
 }
 
 // Dense mode (small user tables: the sweep is cheaper than replaying): AdamW on EVERY row of the table, the batch
 // rows with their gradient (owner map, duplicates by batch scan), all others with g = 0 -- torch.optim's own order of
 // operations.  One wave per table row; workgroup ceil(n_users/4) runs hsk_finish_block.
-template <int V, int NCH, bool FULL, bool GEN>
+template <int V, int NCH, bool FULL, bool GEN, bool PART = false>
 __device__ __forceinline__ void hsk_user_update_dense_body(const hsk_user_lazy_args& a0, int bid) {
   hsk_user_lazy_args a = a0;
   hsk_resolve_step(a.desc, a.rel, a.ctab, a.ctab_len, a.step, a.c);
@@ -778,7 +798,7 @@ __device__ __forceinline__ void hsk_user_update_dense_body(const hsk_user_lazy_a
   const int b0 = n > 0 ? hsk_uniform_i(a.owner[row]) : 0;
   hsk_user_lazy_args a2 = a;
   a2.dupcnt = nullptr;   // the dense path never registered duplicates: batch scan
-  hsk_user_row_chunks<V, NCH, FULL, GEN>(a2, row, b0, n, prow, mrow, vrow, prow, mrow, vrow, lane);
+  hsk_user_row_chunks<V, NCH, FULL, GEN, PART>(a2, row, b0, n, prow, mrow, vrow, prow, mrow, vrow, lane);
   if (n > 0 && lane == 0) {
     a.owner[row] = HSK_OWNER_NONE;
     a.cnt[row] = 0;
@@ -793,9 +813,9 @@ __device__ __forceinline__ void hsk_user_update_dense_body(const hsk_user_lazy_a
   }
 }
 
-template <int V, int NCH, bool FULL, bool GEN>
+template <int V, int NCH, bool FULL, bool GEN, bool PART = false>
 __global__ __launch_bounds__(256) void k_user_update_dense(hsk_user_lazy_args a) {
-  hsk_user_update_dense_body<V, NCH, FULL, GEN>(a, (int)blockIdx.x);
+  hsk_user_update_dense_body<V, NCH, FULL, GEN, PART>(a, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -935,11 +955,19 @@ __global__ __launch_bounds__(256) void k_fill_i32(int* p, long long n, int v) {
   if (i < n) p[i] = v;
 }
 
+// n_part > 1: it32 rows have n_cols + n_part - 1 columns, the positive in the first n_part (k_prep_sample)
 __global__ __launch_bounds__(256) void k_widen_batch(const int* __restrict__ u32, const int* __restrict__ it32,
                                                      long long B, long long total, int64_t* __restrict__ u_out,
-                                                     int64_t* __restrict__ i_out) {
+                                                     int64_t* __restrict__ i_out, int n_cols = 0, int n_part = 1) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < total) i_out[e] = it32[e];
+  if (e < total) {
+    if (n_part > 1) {
+      const long long b = e / n_cols, k = e - b * n_cols;
+      i_out[e] = it32[b * (n_cols + n_part - 1) + (k == 0 ? 0 : k + n_part - 1)];
+    } else {
+      i_out[e] = it32[e];
+    }
+  }
   if (e < B) u_out[e] = u32[e];
 }
 

@@ -474,6 +474,10 @@ class BprMfFusedState:
                    'hsk_bprmf_last_batch')
         return u, i
 
+    def batch_columns(self, batch: int, n_cols: int) -> int:
+        """Columns of the step's internal batch rows (n_cols, or n_cols + P - 1 under the item-partitioned forward)."""
+        return int(self.lib.hsk_bprmf_batch_columns(ctypes.byref(self.st), batch, n_cols))
+
     def last_sort(self, n_entries: int):
         """(perm int32 [n_entries], offsets int32 [n_items + 1]): the item-major index of the last step's batch."""
         perm = torch.empty(n_entries, dtype=torch.int32, device=self.device)

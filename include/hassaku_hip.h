@@ -310,10 +310,17 @@ int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
 int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols,
                          int64_t* u_out, int64_t* i_out, hsk_stream_t stream);
 
+/* Columns of the step's internal batch rows for a batch of this shape: n_cols, or n_cols + P - 1 when the step runs the
+ * item-partitioned forward (csrc/hsk_fwd_part.h: large batches, item tables of a few L2 sizes), whose rows hold the
+ * positive item P times -- unit q of the forward leaves its share of d loss/d s_0 in column q.  The entry index e of
+ * hsk_bprmf_last_sort counts in these columns.  (The reference has no counterpart: its batch is the loader's
+ * [B, 1+N] tensor, data/dataloader.py:92-129.) */
+int64_t hsk_bprmf_batch_columns(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols);
+
 /* Copy of the item-major index the last step built from its batch (debug / parity): perm int32[n_entries] = the
- * batch entries e = b*n_cols + k grouped by item, ascending e inside an item; offsets int32[n_items + 1] = where each
- * item's entries start in perm.  Three kernels build it depending on the shape (csrc/hsk_sort.h); all must return
- * exactly this. */
+ * batch entries e = b*cols + k (cols = hsk_bprmf_batch_columns) grouped by item, ascending e inside an item; offsets
+ * int32[n_items + 1] = where each item's entries start in perm.  Three kernel chains build it depending on the shape
+ * (csrc/hsk_sort.h); all must return exactly this. */
 int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries, int32_t* perm_out, int32_t* offsets_out,
                         hsk_stream_t stream);
 

@@ -472,26 +472,35 @@ def test_multi_step_call_equals_single_steps(ops, shape):
 
 
 @pytest.mark.parametrize('shape', [
-    # (n_users, n_items, D, B, K): which of the three item sorts the step picks
-    (300, 3706, 32, 128, 51),     # k_sort_lds: <= 8192 entries, <= 4 per item on average (BASELINE configs[1] shape)
-    (300, 1682, 32, 128, 2),      # k_sort_lds, 256 entries (BASELINE configs[0] shape)
-    (300, 40, 32, 100, 12),       # k_sort_lds is not eligible (30 entries per item): block radix sort
-    (300, 2000, 32, 64, 101),     # k_sort_lds with popular items: lists far longer than 8 entries (wave rank pass)
-    (300, 5000, 32, 1024, 33),    # > 8192 entries: the four-kernel two-level sort
+    # (n_users, n_items, D, B, K, popular): which of the item sorts the step picks
+    (300, 3706, 32, 128, 51, False),    # k_sort_lds: <= 8192 entries, <= 4 per item on average (BASELINE configs[1] shape)
+    (300, 1682, 32, 128, 2, False),     # k_sort_lds, 256 entries (BASELINE configs[0] shape)
+    (300, 40, 32, 100, 12, False),      # k_sort_lds is not eligible (30 entries per item): block radix sort
+    (300, 2000, 32, 64, 101, True),     # k_sort_lds with popular items: lists far longer than 8 entries (wave rank pass)
+    (300, 5000, 32, 1024, 33, False),   # > 8192 entries: the four-kernel two-level sort
+    (300, 5000, 32, 1024, 33, True),    # ... with lists of thousands of entries
+    (300, 6000, 256, 2048, 17, True),   # item-partitioned forward (P = 2): rows of K + P - 1 columns
 ])
 def test_item_sort_is_the_stable_sort_by_item(ops, shape):
     """perm / offsets of the step's batch == numpy's stable argsort of the item ids, whichever kernel built them."""
-    n_users, n_items, D, B, K = shape
+    n_users, n_items, D, B, K, popular = shape
     rng = np.random.RandomState(11)
     P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
          'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32)}
     st, _ = _fused_state(ops, P, 1e-3, 0.0, B, K)
     u = rng.randint(0, n_users, size=B).astype(np.int64)
     i = rng.randint(0, n_items, size=(B, K)).astype(np.int64)
-    if shape[1] == 2000:                       # a few very popular items
-        i[rng.rand(B, K) < 0.3] = rng.randint(0, 5, size=int((rng.rand(B, K) < 0.3).sum())) if False else 3
+    if popular:                                # a few very popular items
+        i[rng.rand(B, K) < 0.3] = 3
         i[:, 0] = 7
     st.step(dev(u), dev(i))
+    cols = st.batch_columns(B, K)              # the partitioned layout repeats the positive
+    if D == 256:
+        assert cols == K + 1
+    else:
+        assert cols == K
+    i = np.concatenate([np.repeat(i[:, :1], cols - K + 1, axis=1), i[:, 1:]], axis=1)
+    K = cols
     perm, offs = (x.cpu().numpy() for x in st.last_sort(B * K))
     flat = i.reshape(-1)
     want = np.argsort(flat, kind='stable')
