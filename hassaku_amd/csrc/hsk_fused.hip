@@ -455,7 +455,8 @@ template <int V, int NCH, bool FULL, int R, bool APPLY>
 static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, const float* Urows, const int* urow_index,
                                  int K, const hsk_adamw_consts& c, float* gI_out, float* gIb_out, hipStream_t stream,
                                  int64_t n_entries = 0, const hsk_user_lazy_args* ua = nullptr,
-                                 const hsk_ahead_args* aa = nullptr, bool part = false) {
+                                 const hsk_ahead_args* aa = nullptr, int n_part = 1) {
+  const bool part = n_part > 1;
   const int I = (int)st->n_items, D = (int)st->dim;
   if (D % 2 != 0) {
     k_item_update<V, NCH, FULL, R, APPLY><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
@@ -480,7 +481,7 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
   const hsk_item_args ia = {Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias,
                             st->v_item_bias, urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, ipw, c,
                             gI_out, gIb_out, w.touched, w.n_touched, w.last_step_i, (int)st->step,
-                            ua ? ua->desc : nullptr, ua ? ua->rel : 0, w.adam_tab, HSK_ADAM_TAB_LEN};
+                            ua ? ua->desc : nullptr, ua ? ua->rel : 0, w.adam_tab, HSK_ADAM_TAB_LEN, n_part};
   const bool gen = APPLY && st->opt_kind != HSK_OPT_ADAMW;   // APPLY == false never calls the update
   const unsigned nblk = groups * (whole_rows ? 1 : n_slices_pad);
   if (APPLY && ua) {
@@ -514,7 +515,14 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
 #undef HSK_ITEM_USER
     return;
   }
-#define HSK_ITEM_SLICED(VS, GEN, LZ) k_item_update_sliced<APPLY, VS, GEN, LZ><<<nblk, 256, 0, stream>>>(ia)
+#define HSK_ITEM_SLICED(VS, GEN, LZ)                                                   \
+  do {                                                                                 \
+    if (part) {                                                                        \
+      if constexpr (APPLY && V == 4 && FULL && !LZ)                                    \
+        k_item_update_sliced<APPLY, VS, GEN, LZ, true><<<nblk, 256, 0, stream>>>(ia);   \
+    } else                                                                             \
+      k_item_update_sliced<APPLY, VS, GEN, LZ><<<nblk, 256, 0, stream>>>(ia);          \
+  } while (0)
   if (gen) { if (lazy) HSK_ITEM_SLICED(VSC, true, true); else HSK_ITEM_SLICED(VSC, true, false); }
   else     { if (lazy) HSK_ITEM_SLICED(VSC, false, true); else HSK_ITEM_SLICED(VSC, false, false); }
 #undef HSK_ITEM_SLICED
@@ -885,12 +893,12 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       }
       // the item pass reads the user rows from ucur, the user blocks rewrite the table: independent -> one launch
       hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, w.ucur, nullptr, (int)K, c, nullptr, nullptr, stream, total, &ua,
-                                                  &aa, n_part > 1);
+                                                  &aa, n_part);
     } else {
       const bool from_ucur = lazy || D % 2 == 0;
       HSK_STAGE(HSK_STAGE_ITEM, (hsk_launch_item_pass<V, NCH, FULL, R, true>(
                                     st, w, from_ucur ? w.ucur : st->user_emb, from_ucur ? nullptr : w.u32, (int)K, c,
-                                    nullptr, nullptr, stream, total, nullptr)));
+                                    nullptr, nullptr, stream, total, nullptr, nullptr, n_part)));
       if (n_part > 1) {   // partial gradient rows: the PART flavours (V == 4 && FULL by the partition rule)
         if constexpr (V == 4 && FULL) {
           const unsigned gl = (unsigned)hsk_ceil_div(B, 4) + 1, gd = (unsigned)hsk_ceil_div(U, 4) + 1;

@@ -12,10 +12,10 @@
 // recomputed by each of the P units from the same bytes in the same order: identical bits), picks ITS negatives out of
 // the positive's row of ids (one ballot per 64 columns, a list in LDS), weighs them and leaves PARTIAL results: a
 // partial user-row gradient dUp[q][b] (its share of the positive's term included: -gsum_q * I[i_0]), its share -gsum_q
-// of d loss/d s_0, and a partial loss term.  The batch rows have K + P - 1 columns: the positive item P times
-// (k_prep_sample), then the negatives; unit q leaves its share of d loss/d s_0 in column q, so the item pass --
-// unchanged -- meets P entries of the positive item whose weights add up to d loss/d s_0.  The owner's user update
-// adds the P partial rows (hsk_user_row_chunks<PART>).
+// of d loss/d s_0, and a partial loss term.  The batch rows have K + P - 1 columns: the positive item, P - 1 columns
+// that are no entries (-1: the item sort skips them), then the negatives (k_prep_sample); unit q leaves its share of
+// d loss/d s_0 in column q of g_s, and the item pass adds the P shares when it meets the positive's entry
+// (hsk_entry_weight).  The owner's user update adds the P partial rows (hsk_user_row_chunks<PART>).
 //
 // Lazy user rows: the ahead-of-time catch-up (hsk_user_ahead_body, workgroups of this launch for the NEXT batch) keeps
 // the rows current; a row that is behind all the same (no hint, first step) is replayed in registers by each of its P

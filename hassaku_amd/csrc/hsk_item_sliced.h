@@ -49,11 +49,22 @@ struct hsk_item_args {
   const int* touched; const int* n_touched; int* last_step_i; int step;   // LAZY only
   const hsk_step_desc* desc; int rel;   // graph replay: step = desc->step0 + rel + 1, c from ctab
   const float2* ctab; int ctab_len;
+  int n_part;             // PART kernels (item-partitioned forward): d loss/d s_0 of a positive = g_s[e] + .. + g_s[e + n_part-1]
 };
+
+// d loss / d score of entry e of batch position bpos.  PART: the forward's n_part units left their shares of the
+// positive's weight in the first n_part columns of the row (column 0 is the positive's entry, the others are no entries)
+template <bool PART>
+__device__ __forceinline__ float hsk_entry_weight(const hsk_item_args& a, int e, int bpos) {
+  float g = a.g_s[e];
+  if (PART && e == bpos * a.K)
+    for (int q = 1; q < a.n_part; ++q) g += a.g_s[e + q];
+  return g;
+}
 
 // VS floats per lane: slice width = 64*VS floats; GEN: see hsk_adamw_update; LAZY: only the items in `touched`.
 // `bid` = workgroup index inside the item pass (the launch may carry other workgroups in front, see k_item_user).
-template <bool APPLY, int VS, bool GEN, bool LAZY>
+template <bool APPLY, int VS, bool GEN, bool LAZY, bool PART = false>
 __device__ __forceinline__ void hsk_item_sliced_body(const hsk_item_args& a, int bid) {
   const float* __restrict__ Uw = a.Uw;
   float* __restrict__ Iw = a.Iw;
@@ -116,8 +127,9 @@ __device__ __forceinline__ void hsk_item_sliced_body(const hsk_item_args& a, int
       float myg = 0.f;
       if (lane < nr) {
         const int e = perm[c0 + lane];
-        myg = g_s[e];
-        myu = u32 ? u32[e / K] : e / K;   // NULL: user rows are laid out by batch position (ucur)
+        const int bpos = e / K;
+        myg = PART ? hsk_entry_weight<true>(a, e, bpos) : g_s[e];
+        myu = u32 ? u32[bpos] : bpos;   // NULL: user rows are laid out by batch position (ucur)
       }
       gb_lane += myg;
       for (int j = 0; j < nr; j += HSK_ITEM_MLP) {
@@ -231,9 +243,9 @@ __device__ __forceinline__ void hsk_item_row_body(const hsk_item_args& a, int bi
   if (LAZY && lane == 0) a.last_step_i[i] = step;
 }
 
-template <bool APPLY, int VS, bool GEN, bool LAZY = false>
+template <bool APPLY, int VS, bool GEN, bool LAZY = false, bool PART = false>
 __global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
-  hsk_item_sliced_body<APPLY, VS, GEN, LAZY>(a, (int)blockIdx.x);
+  hsk_item_sliced_body<APPLY, VS, GEN, LAZY, PART>(a, (int)blockIdx.x);
 }
 
 // The item pass and the owners' user-row update in ONE launch: the first n_user_blocks workgroups (a multiple of 8, so
@@ -259,7 +271,7 @@ void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int
   int bid = (int)blockIdx.x;
   if (PART && n_ahead_blocks < 0) {   // PART: -n_ahead_blocks item workgroups first, the user workgroups behind them
     if (bid < -n_ahead_blocks) {
-      hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, bid);
+      hsk_item_sliced_body<true, VS, GEN, LAZYI, PART>(ia, bid);
       return;
     }
     bid -= -n_ahead_blocks;
@@ -276,7 +288,7 @@ void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int
     hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, bid - n_user_blocks);
     return;
   }
-  hsk_item_sliced_body<true, VS, GEN, LAZYI>(ia, bid - n_user_blocks - (LAZYI ? n_ahead_blocks : 0));
+  hsk_item_sliced_body<true, VS, GEN, LAZYI, PART>(ia, bid - n_user_blocks - (LAZYI ? n_ahead_blocks : 0));
 }
 
 // small batches: whole-row item workgroups, interleaved with the ahead workgroups

@@ -13,8 +13,9 @@ __global__ __launch_bounds__(256) void k_prep_external(const int64_t* __restrict
                                                        int* __restrict__ owner, int* __restrict__ cnt,
                                                        int32_t* status, int* __restrict__ stamp = nullptr,
                                                        int stamp_val = 0, int n_part = 1) {
-  // n_part > 1 (item-partitioned forward, hsk_fwd_part.h): rows of K + n_part - 1 columns, the positive item in the
-  // first n_part of them (unit q of the forward leaves its share of d loss/d s_0 in column q)
+  // n_part > 1 (item-partitioned forward, hsk_fwd_part.h): rows of K + n_part - 1 columns; column 0 is the positive item,
+  // columns 1 .. n_part-1 hold -1 (no entry: the item sort skips them) -- unit q of the forward leaves its share of
+  // d loss/d s_0 in column q of g_s, the item pass adds the n_part shares when it meets the positive's entry
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * K;
   if (e < total) {
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(256) void k_prep_external(const int64_t* __restrict
       const long long b = e / K, k = e - b * K;
       int* row = it32 + b * (K + n_part - 1);
       if (k == 0)
-        for (int q = 0; q < n_part; ++q) row[q] = it;
+        for (int q = 0; q < n_part; ++q) row[q] = q ? -1 : it;
       else
         row[k + n_part - 1] = it;
     } else {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
                                                      hsk_alias at = hsk_alias{nullptr, nullptr},
                                                      const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0,
                                                      int* __restrict__ stamp = nullptr, int n_part = 1) {
-  // n_part > 1: rows of K + n_part - 1 columns, the positive item in the first n_part (see k_prep_external)
+  // n_part > 1: rows of K + n_part - 1 columns, the positive in column 0, -1 in columns 1 .. n_part-1 (see k_prep_external)
   // stamp (optional): stamp[u] = the (1-based) step this batch is trained on, for every user of the batch -- how a
   // kernel of that step tells the rows being updated from the rows it may bring up to date ahead of time
   // b_offset: offset added to the batch position in the RNG counter (a slice of a larger global batch).
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
                                       stream_id, status, at);
     row[n_part + n] = neg;
   }
-  if (lane < n_part) row[lane] = ipos;
+  if (lane < n_part) row[lane] = lane ? -1 : ipos;
   if (lane == 0) {
     u32[b] = u;
     if (owner) {

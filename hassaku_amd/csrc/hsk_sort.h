@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
     cnt[2 * ipb + j] += start;
     cnt[3 * ipb + j] += start;
   }
-  if (b == p.n_buckets - 1 && tid == 0) offsets[n_items] = n_entries;
+  if (b == p.n_buckets - 1 && tid == 0) offsets[n_items] = end;   // = the entries with an item id (negative ids: no entry)
   if (touched && tid == 0) tmeta[1] = atomicAdd(n_touched, tmeta[0]);
   __syncthreads();
   if (touched)

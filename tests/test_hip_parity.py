@@ -499,12 +499,14 @@ def test_item_sort_is_the_stable_sort_by_item(ops, shape):
         assert cols == K + 1
     else:
         assert cols == K
-    i = np.concatenate([np.repeat(i[:, :1], cols - K + 1, axis=1), i[:, 1:]], axis=1)
-    K = cols
-    perm, offs = (x.cpu().numpy() for x in st.last_sort(B * K))
+    # partitioned rows: the positive, cols - K columns that are no entries (the sort skips them), the negatives
+    i = np.concatenate([i[:, :1], np.full((B, cols - K), -1, dtype=np.int64), i[:, 1:]], axis=1)
     flat = i.reshape(-1)
-    want = np.argsort(flat, kind='stable')
-    assert np.array_equal(perm, want)
+    n_ent = int((flat >= 0).sum())
+    perm, offs = (x.cpu().numpy() for x in st.last_sort(B * cols))
+    want = np.argsort(np.where(flat < 0, n_items, flat), kind='stable')[:n_ent]
+    assert np.array_equal(perm[:n_ent], want)
+    flat = flat[flat >= 0]
     assert np.array_equal(offs, np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=n_items))]))
     st.check_status()
 
