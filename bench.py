@@ -52,9 +52,10 @@ WORKLOADS = {
 EVAL_SHAPES = {'ml10m': (69878, 10677, 512, 82), 'lfm2b': (16384, 131072, 512, 120)}   # U, I, D, positives per user
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 ICACHE_GATHER_GBS = 8600.0   # same guide, "Indexed rows": uniformly random rows of an Infinity-Cache-resident table
+L2_GATHER_GBS = 17800.0      # same table: rows shared by every workgroup of an XCD (its L2), 16.8-18.8 TB/s chip-wide
 HBM_GATHER_GBS = 5750.0      # same guide: random 2.3 KB rows of a table far beyond the Infinity Cache, 5.7-5.8 TB/s
 MFMA_FP32_TFLOPS = 157.0     # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32; no xf32 on gfx950)
-PROFILE_DIR = {'ml10m': 'r2_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2_ml1m', 'ml100k': 'r2_ml100k'}  # committed rocprofv3 summaries
+PROFILE_DIR = {'ml10m': 'r2b_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2_ml1m', 'ml100k': 'r2_ml100k'}  # committed rocprofv3 summaries
 LR, WD = 3e-4, 4e-5          # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
@@ -210,7 +211,8 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     out = dict(value=steps * B * N * world / elapsed, ms_per_step=elapsed * 1e3 / steps,
                fwd_us=(fwd_ms * 1e3 / fwd_n) if fwd_n else None, fwd_launches=int(fwd_n), loss=loss, B=B, N=N, D=D,
                data=data, csr=csr, nnz=nnz, steps=steps, warmup=warmup, graph_replays=n_replays, pure_us=pure_us,
-               lazy_users=bool(st.st.lazy_users) if comm is None else True)
+               lazy_users=bool(st.st.lazy_users) if comm is None else True,
+               parts=(st.batch_columns(B, N + 1) - N) if comm is None else 1)
     if all_stages:
         out['stage_us_per_step'] = {k: v[0] * 1e3 / max(v[1], 1) for k, v in timing.items()}
     del st
@@ -233,25 +235,39 @@ def roofline_of(workload, r):
     d = r['data']
     table_mb = 4.0 * r['D'] * d.n_items / 1e6
     cached = table_mb < 200.0          # 256 MiB Infinity Cache
-    traffic, src = pmc_traffic('k_fwd_ugrad', workload)
-    out = {'bound': 'infinity-cache' if cached else 'hbm',
-           'kernel': 'k_fwd_ugrad (gather + scores + BPR + user-row grad)',
-           'achieved': achieved, 'unit': 'GB/s',
-           'peak': ICACHE_GATHER_GBS if cached else HBM_PEAK_GBS,
-           'frac': achieved / (ICACHE_GATHER_GBS if cached else HBM_PEAK_GBS),
-           'peak_source': ('MI355X_MICROARCH.md: 8.6 TB/s measured for uniformly random row gathers from an Infinity-Cache-'
-                           'resident table (the %.1f MB item table is cache-resident; FETCH_SIZE counts cache hits, so true '
-                           'HBM bytes of this kernel are not observable)' % table_mb) if cached else
-                          'MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (guide measures 6.29 TB/s streaming, 5.7-5.8 TB/s for random 2.3 KB rows)',
+    parts = r.get('parts', 1)
+    traffic, src = pmc_traffic('k_fwd_part' if parts > 1 else 'k_fwd_ugrad', workload)
+    if parts > 1:
+        # item-partitioned forward (csrc/hsk_fwd_part.h): an XCD gathers from its 1/P of the item table only, most of it
+        # resident in its own 4 MB L2 -- the bound is the L2s' gather rate
+        bound, peak = 'l2', L2_GATHER_GBS
+        kernel = 'k_fwd_part, P = %d (gather + scores + BPR + partial user-row grads; the next batch\'s lazy user rows brought up to date by workgroups of the same launch)' % parts
+        peak_source = ('MI355X_MICROARCH.md, "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs\' L2s (mid-point); '
+                       'each XCD gathers from %.1f MB of the %.1f MB item table' % (table_mb / parts, table_mb))
+    elif cached:
+        bound, peak = 'infinity-cache', ICACHE_GATHER_GBS
+        kernel = 'k_fwd_ugrad (gather + scores + BPR + user-row grad)'
+        peak_source = ('MI355X_MICROARCH.md: 8.6 TB/s measured for uniformly random row gathers from an Infinity-Cache-'
+                       'resident table (the %.1f MB item table is cache-resident; FETCH_SIZE counts cache hits, so true '
+                       'HBM bytes of this kernel are not observable)' % table_mb)
+    else:
+        bound, peak = 'hbm', HBM_PEAK_GBS
+        kernel = 'k_fwd_ugrad (gather + scores + BPR + user-row grad)'
+        peak_source = 'MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (guide measures 6.29 TB/s streaming, 5.7-5.8 TB/s for random 2.3 KB rows)'
+    out = {'bound': bound, 'kernel': kernel, 'achieved': achieved, 'unit': 'GB/s', 'peak': peak, 'frac': achieved / peak,
+           'peak_source': peak_source,
            'frac_of_hbm_spec_8000': achieved / HBM_PEAK_GBS,
            'traffic': traffic, 'traffic_source': src,
            'avg_us': r['fwd_us'], 'launches': r['fwd_launches'], 'algorithmic_bytes_per_launch': by,
            'item_table_MB': table_mb}
+    if parts > 1:
+        out['frac_of_infinity_cache_gather_8600'] = achieved / ICACHE_GATHER_GBS
     if not cached:
         out['frac_of_measured_hbm_gather_5750'] = achieved / HBM_GATHER_GBS
     if r.get('pure_us'):
-        # avg_us above includes the in-register replay of the user rows' pending AdamW steps (VALU work, ~9 us at the
-        # ml10m shape); with that replay in a launch of its own the kernel is the gather alone:
+        # avg_us above includes the replay of lazily updated user rows' pending AdamW steps (VALU work: in the
+        # wave's registers, or -- partitioned forward -- by workgroups of the same launch for the NEXT batch's rows;
+        # ~9-12 us at the ml10m shape); with that replay in a launch of its own the kernel is the gather alone:
         pa = by / (r['pure_us'] * 1e-6) / 1e9
         out['pure_gather'] = {'avg_us': r['pure_us'], 'achieved': pa, 'frac': pa / out['peak'],
                               'frac_of_hbm_spec_8000': pa / HBM_PEAK_GBS,

@@ -791,8 +791,10 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
           n_ahead = (int)hsk_align_up(hsk_ceil_div(aa.n, 4), 8);
         }
         const unsigned n_unit = 8u * (unsigned)hsk_ceil_div(hsk_ceil_div(B, 4), 8 / n_part);
-        static const int ahead_last = getenv("HSK_AHEAD_LAST") ? atoi(getenv("HSK_AHEAD_LAST")) : 0;
-        const hsk_part_args pa = {n_part, (int)st->n_items, w.part_stride, n_ahead, ahead_last ? (int)n_unit : 0};
+        // HSK_AHEAD_MIX=1: the ahead octets interleaved with the unit octets instead of leading (measured: 88 vs 86 us)
+        static const int ahead_mix = getenv("HSK_AHEAD_MIX") ? atoi(getenv("HSK_AHEAD_MIX")) : 0;
+        const int stride = (ahead_mix && n_ahead > 0) ? (int)(n_unit / 8) / (n_ahead / 8) : 0;
+        const hsk_part_args pa = {n_part, (int)st->n_items, w.part_stride, n_ahead, stride};
         const unsigned grid = (unsigned)n_ahead + n_unit;
 #define HSK_LAUNCH_FWD_PART(LK, GEN)                                                                                 \
   if (capturing)                                                                                                    \

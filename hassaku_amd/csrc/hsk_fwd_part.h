@@ -28,7 +28,9 @@ struct hsk_part_args {
   int n_items;
   long long part_stride;         // floats between the partial planes of dUp
   int n_ahead_blocks;            // workgroups that run hsk_user_ahead_body (a multiple of 8)
-  int n_unit_blocks;             // > 0: the ahead workgroups FOLLOW this many unit workgroups; 0: they lead
+  int ahead_stride;              // > 0: one OCTET of ahead workgroups follows every `ahead_stride` octets of unit
+                                 // workgroups (octets: a unit workgroup keeps blockIdx % 8 == its own index % 8), the
+                                 // replay -- VALU work -- runs beside the gathers all along; 0: the ahead workgroups lead
 };
 #define HSK_PART_LIST_MAX 256    // negatives per positive (the partition rule keeps n_neg <= 256)
 
@@ -41,10 +43,18 @@ __global__ __launch_bounds__(256) void k_fwd_part(const float* __restrict__ Uw, 
                                                   hsk_ahead_args aa) {
   static_assert(LOSS == HSK_LOSS_BPR || LOSS == HSK_LOSS_BCE, "the sampled softmax needs all negatives in one wave");
   int bid = (int)blockIdx.x;
-  if (pa.n_unit_blocks > 0) {
-    if (bid >= pa.n_unit_blocks) {
-      hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, bid - pa.n_unit_blocks);
-      return;
+  if (pa.ahead_stride > 0) {
+    const int o = bid >> 3, r = bid & 7, n_ao = pa.n_ahead_blocks >> 3;
+    const int period = pa.ahead_stride + 1, full = n_ao * period;
+    if (o < full) {
+      const int k = o / period, j = o - k * period;
+      if (j == pa.ahead_stride) {
+        hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, k * 8 + r);
+        return;
+      }
+      bid = (k * pa.ahead_stride + j) * 8 + r;
+    } else {
+      bid = (n_ao * pa.ahead_stride + (o - full)) * 8 + r;
     }
   } else {
     if (bid < pa.n_ahead_blocks) {
@@ -62,52 +72,69 @@ __global__ __launch_bounds__(256) void k_fwd_part(const float* __restrict__ Uw, 
 
   using Row = hsk_row<V, NCH>;
   const int* __restrict__ irow = it32 + (long long)b * K;
-  const int u = hsk_uniform_i(u32[b]);
-  const int i0 = hsk_uniform_i(irow[0]);
+  // Loads in three rounds instead of a chain of six: (1) what depends on b only -- the user id, the positive, the row of
+  // item ids; (2) the user row, the positive's row, the user's lazy-update state and the first item rows; (3) the rest.
+  const int u_v = u32[b];
+  const int i0_v = irow[0];
+  int idv[HSK_PART_LIST_MAX / 64];
+#pragma unroll
+  for (int r = 0; r < HSK_PART_LIST_MAX / 64; ++r) {
+    const int c = P + r * 64 + lane;
+    idv[r] = (c < K) ? irow[c] : -1;
+  }
+  const int u = hsk_uniform_i(u_v);
+  const int i0 = hsk_uniform_i(i0_v);
+  Row ur, r0, acc;
+  hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
+  hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  int done_v = 0, own_v = 0;
+  if (lz.mU) {
+    done_v = lz.last_step[u];
+    own_v = lz.owner[u];
+  }
+  const float bias0 = Ib ? Ib[i0] : 0.f;
   // this unit's negatives: (item id, column) of the ids in [lo, hi), in column order
   __shared__ int lst_id[4][HSK_PART_LIST_MAX], lst_col[4][HSK_PART_LIST_MAX];
   const int lo = (int)(((long long)q * pa.n_items + P - 1) / P), hi = (int)(((long long)(q + 1) * pa.n_items + P - 1) / P);
   int n_mine = 0;
-  for (int c0 = P; c0 < K; c0 += 64) {
-    const int c = c0 + lane;
-    const int id = (c < K) ? irow[c] : -1;
-    const bool mine = id >= lo && id < hi;
+#pragma unroll
+  for (int r = 0; r < HSK_PART_LIST_MAX / 64; ++r) {
+    const bool mine = idv[r] >= lo && idv[r] < hi;
     const unsigned long long m = __ballot(mine);
     if (mine) {
       const int pos = n_mine + __popcll(m & ((1ull << lane) - 1ull));
-      lst_id[wave][pos] = id;
-      lst_col[wave][pos] = c;
+      lst_id[wave][pos] = idv[r];
+      lst_col[wave][pos] = P + r * 64 + lane;
     }
     n_mine += __popcll(m);
   }
   __builtin_amdgcn_wave_barrier();
-  const int beg = 0, end = n_mine;
 
-  Row ur, r0, acc;
-  hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
-  hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  int kc = 0;
+  int nr = min(64, n_mine);
+  int myidx = (lane < nr) ? lst_id[wave][lane] : i0;
+  int mycol = (lane < nr) ? lst_col[wave][lane] : 0;
+  Row bufA[R], bufB[R];
+  auto prefetch = [&](Row(&buf)[R], int j) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (j + r < nr)
+        hsk_row_load<V, NCH, FULL>(buf[r], Iw + (long long)hsk_readlane_i(myidx, j + r) * D, lane, D);
+  };
+  prefetch(bufA, 0);
+  float mybias = Ib ? Ib[myidx] : 0.f;
+
   if (lz.mU)
-    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, q == 0);
+    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, q == 0, hsk_uniform_i(done_v), hsk_uniform_i(own_v));
   else if (lz.ucur && q == 0)
     hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
   hsk_row_zero(acc);
-  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
+  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + bias0;
 
   float gsum = 0.f;
   double lsum = 0.0;
-  for (int kc = beg; kc < end; kc += 64) {
-    const int nr = min(64, end - kc);
-    const int myidx = (lane < nr) ? lst_id[wave][kc + lane] : i0;
-    const int mycol = (lane < nr) ? lst_col[wave][kc + lane] : 0;
-    const float mybias = Ib ? Ib[myidx] : 0.f;
+  while (true) {
     float gv = 0.f, xv = 0.f;
-    Row bufA[R], bufB[R];
-    auto prefetch = [&](Row(&buf)[R], int j) {
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (j + r < nr)
-          hsk_row_load<V, NCH, FULL>(buf[r], Iw + (long long)hsk_readlane_i(myidx, j + r) * D, lane, D);
-    };
     auto process = [&](Row(&buf)[R], int j) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -128,7 +155,6 @@ __global__ __launch_bounds__(256) void k_fwd_part(const float* __restrict__ Uw, 
         }
       }
     };
-    prefetch(bufA, 0);
     for (int j = 0; j < nr; j += 2 * R) {
       prefetch(bufB, j + R);
       process(bufA, j);
@@ -139,6 +165,13 @@ __global__ __launch_bounds__(256) void k_fwd_part(const float* __restrict__ Uw, 
       g_s[(long long)b * K + mycol] = gv;
       lsum += (double)hsk_softplus(LOSS == HSK_LOSS_BPR ? -xv : xv);
     }
+    kc += 64;
+    if (kc >= n_mine) break;
+    nr = min(64, n_mine - kc);
+    myidx = (lane < nr) ? lst_id[wave][kc + lane] : i0;
+    mycol = (lane < nr) ? lst_col[wave][kc + lane] : 0;
+    prefetch(bufA, 0);
+    mybias = Ib ? Ib[myidx] : 0.f;
   }
   float gp;   // this unit's share of -d loss/d s_0
   if (LOSS == HSK_LOSS_BPR) {

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_ugrad_wg(const float* __restric
   // lazily updated user row: every wave replays the pending steps on its own copy (identical results), wave 0
   // publishes the current row for the item pass
   if (lz.mU)
-    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, sub == 0);
+    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, sub == 0, hsk_uniform_i(lz.last_step[u]),
+                                       hsk_uniform_i(lz.owner[u]));
   else if (lz.ucur && sub == 0)
     hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
   hsk_row_zero(acc);

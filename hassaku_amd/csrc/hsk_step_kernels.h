@@ -47,12 +47,11 @@ struct hsk_lazy_user_args {
 
 #define HSK_DUP_MAX 8   // duplicate entries of one user that are listed for the owner (more: batch scan)
 
+// `done` / `own`: last_step[u] and owner[u], loaded by the caller (early, together with its other loads)
 template <int V, int NCH, bool FULL>
 __device__ __forceinline__ void hsk_user_row_current(hsk_row<V, NCH>& p, int u, int b, int B, int D, int lane,
-                                                     const hsk_lazy_user_args& lz, bool publish) {
+                                                     const hsk_lazy_user_args& lz, bool publish, int done, int own) {
   const int step = lz.desc ? lz.desc->step0 + lz.rel + 1 : lz.step;
-  const int done = hsk_uniform_i(lz.last_step[u]);
-  const int own = hsk_uniform_i(lz.owner[u]);
   if (done < step - 1) {
     hsk_row<V, NCH> m, v;
     hsk_row_load<V, NCH, FULL>(m, lz.mU + (long long)u * D, lane, D);
@@ -123,7 +122,8 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
   hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
   hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
   if (lz.mU)
-    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, true);
+    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, true, hsk_uniform_i(lz.last_step[u]),
+                                       hsk_uniform_i(lz.owner[u]));
   else if (lz.ucur)   // dense user updates: the rows are current; the item pass still reads them by batch position
     hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
   hsk_row_zero(acc);
