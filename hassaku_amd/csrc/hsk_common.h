@@ -101,6 +101,20 @@ template <int V>
 __device__ __forceinline__ void hsk_stg(float* p, const hsk_vec<V>& x) {
   *reinterpret_cast<hsk_vec<V>*>(p) = x;
 }
+// non-temporal store: a stream that nobody re-reads soon (AdamW moments of rows brought up to date) should not sit
+// dirty in the Infinity Cache and drain into HBM under the next kernel's gathers
+template <int V>
+__device__ __forceinline__ void hsk_stg_nt(float* p, const hsk_vec<V>& x) {
+  typedef float vf __attribute__((ext_vector_type(V)));
+  vf t;
+#pragma unroll
+  for (int i = 0; i < V; ++i) t[i] = x.v[i];
+  __builtin_nontemporal_store(t, reinterpret_cast<vf*>(p));
+}
+template <>
+__device__ __forceinline__ void hsk_stg_nt<1>(float* p, const hsk_vec<1>& x) {
+  __builtin_nontemporal_store(x.v[0], p);
+}
 template <int V>
 __device__ __forceinline__ hsk_vec<V> hsk_zero() {
   hsk_vec<V> r;

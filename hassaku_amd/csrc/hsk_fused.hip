@@ -631,7 +631,10 @@ static int hsk_discard_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, hipStr
 // D=512: 243 us/step forked before, 231 us forked after, 252 us without prefetch).  A small forward kernel leaves
 // the chip mostly idle and the step is launch-latency-bound: fork as early as possible (B=128: 65 us before, 97 us
 // after, 83 us without).
-static bool hsk_pf_early(int64_t B) { return B < 2048; }
+static bool hsk_pf_early(int64_t B) {
+  static const int env = getenv("HSK_PF_EARLY") ? atoi(getenv("HSK_PF_EARLY")) : -1;   // experiments: 0 / 1 force
+  return env >= 0 ? env != 0 : B < 2048;
+}
 #define HSK_PREFETCH_MIN_ENTRIES 4096
 
 // true: this step will fork a prefetch (hint present and worth it)

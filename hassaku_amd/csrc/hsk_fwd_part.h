@@ -26,7 +26,7 @@
 struct hsk_part_args {
   int n_part;                    // P: 2, 4 or 8; partition q = items [ceil(q I / P), ceil((q + 1) I / P))
   int n_items;
-  long long part_stride;         // floats between the partial planes of dUp
+  long long part_stride;         // (unused: the partial rows of a batch position lie side by side, [b][q][D])
   int n_ahead_blocks;            // workgroups that run hsk_user_ahead_body (a multiple of 8)
   int ahead_stride;              // > 0: one OCTET of ahead workgroups follows every `ahead_stride` octets of unit
                                  // workgroups (octets: a unit workgroup keeps blockIdx % 8 == its own index % 8), the
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_fwd_part(const float* __restrict__ Uw, 
     if (q == 0 && lane == 0) lsum += (double)hsk_softplus(-s0);
   }
   hsk_row_axpy(acc, -gp, r0);
-  hsk_row_store<V, NCH, FULL>(acc, dUp + (long long)q * pa.part_stride + (long long)b * D, lane, D);
+  hsk_row_store<V, NCH, FULL>(acc, dUp + ((long long)b * P + q) * D, lane, D);   // [b][q][D]
   const double l = hsk_wave_sum_f64(lsum);
   if (lane == 0) {
     g_s[(long long)b * K + q] = -gp;

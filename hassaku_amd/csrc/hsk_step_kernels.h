@@ -2,6 +2,12 @@
 #pragma once
 #include "hsk_rows.h"
 
+#ifndef HSK_REPLAY_NT
+#define HSK_REPLAY_NT 0   // 1 / 2: moments / whole rows of replayed rows leave with non-temporal stores (hsk_stg_nt).
+                          // Measured at the hbm shape (forward behind the lazy item catch-up): 216 -> 210 us forward,
+                          // the catch-up itself slower: off.
+#endif
+
 __device__ __forceinline__ hsk_adamw_consts hsk_consts_at(const hsk_adamw_consts& base, const float2* __restrict__ tab,
                                                           int tab_len, int t) {
   hsk_adamw_consts c = base;
@@ -459,9 +465,18 @@ __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, floa
 #pragma unroll
       for (int q = 0; q < VV; ++q) hsk_adamw_replay<GEN>(p.v[q], m.v[q], v.v[q], c);
     }
+#if HSK_REPLAY_NT > 1
+    hsk_stg_nt<VV>(prow + d0, p);
+#else
     hsk_stg<VV>(prow + d0, p);
+#endif
+#if HSK_REPLAY_NT
+    hsk_stg_nt<VV>(mrow + d0, m);
+    hsk_stg_nt<VV>(vrow + d0, v);
+#else
     hsk_stg<VV>(mrow + d0, m);
     hsk_stg<VV>(vrow + d0, v);
+#endif
   }
 }
 
@@ -617,19 +632,19 @@ struct hsk_user_lazy_args {
   const hsk_step_desc* desc; int rel;   // graph replay: step = desc->step0 + rel + 1, c from ctab
   const float2* ctab; int ctab_len;
   int n_part; long long part_stride;   // item-partitioned forward: a gradient row is the sum of n_part partial rows,
-                                       // part_stride floats apart (n_part <= 1: one row)
+                                       // laid out [b][q][D] (the n_part rows of a batch position side by side)
 };
 
 // gradient chunk of batch position b: the partial rows added in partition order
 template <int V>
 __device__ __forceinline__ hsk_vec<V> hsk_grad_chunk(const hsk_user_lazy_args& a, int b, int off) {
-  const float* src = a.dUb + (long long)b * a.D + off;
+  const float* src = a.dUb + (long long)b * a.n_part * a.D + off;
   hsk_vec<V> g = hsk_ldg<V>(src);
   for (int q0 = 1; q0 < a.n_part; q0 += 3) {   // three loads in flight, then their sum in partition order
     hsk_vec<V> t[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      t[j] = (q0 + j < a.n_part) ? hsk_ldg<V>(src + (long long)(q0 + j) * a.part_stride) : hsk_zero<V>();
+      t[j] = (q0 + j < a.n_part) ? hsk_ldg<V>(src + (long long)(q0 + j) * a.D) : hsk_zero<V>();
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll

@@ -13,7 +13,8 @@
 #include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
-constexpr int D = 512, I = 10677, B = 4096, K = 101;
+constexpr int D = 512, B = 4096, K = 101;
+static int I = 10677;   // argv[1]: item rows (2000000 = the hbm workload: nothing cached, table values left zero)
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL, int RM = 0xF>
@@ -97,17 +98,19 @@ float run(const float* Iw, const float* ucur, const float* Ib, const int* it, co
   return ms * 1e3f;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) I = atoi(argv[1]);
+  const bool big = I > 100000;
   float *Iw, *ucur, *Ib, *g_s, *dUp, *gsum_p; int* it; unsigned char* off; double* loss_p;
   CK(hipMalloc(&Iw, (size_t)I * D * 4)); CK(hipMalloc(&ucur, (size_t)B * D * 4)); CK(hipMalloc(&Ib, I * 4));
   CK(hipMalloc(&it, B * K * 4)); CK(hipMalloc(&g_s, B * K * 4)); CK(hipMalloc(&dUp, (size_t)8 * B * D * 4));
   CK(hipMalloc(&gsum_p, 8 * B * 4)); CK(hipMalloc(&loss_p, 8 * B * 8)); CK(hipMalloc(&off, B * 9));
-  std::vector<float> hI((size_t)I * D), hU((size_t)B * D), hb(I);
+  std::vector<float> hI(big ? 1 : (size_t)I * D), hU((size_t)B * D), hb(I);
   srand(1);
   for (auto& v : hI) v = (rand() / (float)RAND_MAX - 0.5f) * 0.3f;
   for (auto& v : hU) v = (rand() / (float)RAND_MAX - 0.5f) * 0.3f;
   for (auto& v : hb) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
-  CK(hipMemcpy(Iw, hI.data(), hI.size() * 4, hipMemcpyHostToDevice));
+  if (big) CK(hipMemset(Iw, 0, (size_t)I * D * 4)); else CK(hipMemcpy(Iw, hI.data(), hI.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(ucur, hU.data(), hU.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Ib, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -116,12 +119,12 @@ int main() {
   std::vector<unsigned char> ho(B * 9);
   std::vector<float> ref((size_t)B * D), got((size_t)8 * B * D), refg(B * K), gotg(B * K);
   const int Ps[4] = {1, 2, 4, 8};
-  for (int pi = 0; pi < 4; ++pi) {
+  for (int pi = 0; pi < (big ? 1 : 4); ++pi) {
     const int P = Ps[pi];
     for (int Rsel = 0; Rsel < 2; ++Rsel) {
       float tot = 0, best = 1e9;
       for (int rep = 0; rep < 12; ++rep) {
-        for (auto& v : hi) v = rand() % I;
+        for (auto& v : hi) v = (int)((((long long)rand() << 15) ^ rand()) % I);
         for (int b = 0; b < B; ++b) {   // bucket the negatives of a positive by partition
           int* r = &hi[b * K];
           std::stable_sort(r + 1, r + K, [&](int a, int c) { return (long long)a * P / I < (long long)c * P / I; });
