@@ -14,6 +14,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, 'liboracle.so')
+# sanitizer build of the same source (-fsanitize host build of the CPU restatement): built by
+# build_sanitized(), loaded instead of liboracle.so when HSK_ORACLE_SO names it (tests/test_oracle_sanitized.py runs
+# the golden-vector tests against it in a child process with libasan preloaded)
+SAN_SO_PATH = os.path.join(_HERE, 'liboracle_san.so')
 _lib = None
 
 
@@ -24,12 +28,22 @@ def build(force: bool = False):
     return SO_PATH
 
 
+def build_sanitized():
+    src = os.path.join(_HERE, 'bprmf_oracle.c')
+    if not os.path.isfile(SAN_SO_PATH) or os.path.getmtime(SAN_SO_PATH) < os.path.getmtime(src):
+        subprocess.check_call(['gcc', '-O1', '-g', '-fno-omit-frame-pointer', '-fsanitize=address,undefined',
+                               '-fno-sanitize-recover=undefined', '-ffp-contract=off', '-fPIC', '-shared', '-o',
+                               SAN_SO_PATH, src, '-lm'])
+    return SAN_SO_PATH
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.isfile(SO_PATH):
+        path = os.environ.get('HSK_ORACLE_SO') or SO_PATH
+        if path == SO_PATH and not os.path.isfile(SO_PATH):
             build()
-        _lib = ctypes.CDLL(SO_PATH)
+        _lib = ctypes.CDLL(path)
         _lib.orc_bpr_loss_grad.restype = c_double
         _lib.orc_count_bad_negatives.restype = c_int64
     return _lib
