@@ -33,6 +33,16 @@
 // sampler that buckets a batch's negatives and the step that trains on it must agree.  HSK_FWD_PARTS=1 turns it off,
 // =2/4/8 forces a partition count (where the shape allows partitions at all).
 #define HSK_PART_MAX 8
+// Grouped preparation (small batches, replayed graphs): the batches of G consecutive steps are sampled and sorted by ONE
+// launch each (k_prep_sample_group, k_sort_lds over G workgroups) -- at B = 128 a step is four ~5 us kernels, two of which
+// only prepare the next batch.  The per-batch buffers of a set then hold G batches; eager steps use slot 0.
+#define HSK_GROUP_MAX 8
+static int hsk_group_rule(int64_t n_items, int64_t dim, int64_t batch, int64_t n_cols) {
+  static const int env = getenv("HSK_GROUP") ? atoi(getenv("HSK_GROUP")) : HSK_GROUP_MAX;
+  if (env <= 1 || dim % 2 != 0 || batch > 1024 || !hsk_sort_lds_fits(n_items, batch * n_cols)) return 1;
+  return std::min(env, HSK_GROUP_MAX);
+}
+
 static inline int64_t hsk_part_cols(int64_t n_cols, int n_part) { return n_cols + (n_part > 1 ? n_part - 1 : 0); }
 static int hsk_part_rule(int64_t n_items, int64_t dim, int64_t batch, int64_t n_neg, bool lazy_items) {
   static const int env = getenv("HSK_FWD_PARTS") ? atoi(getenv("HSK_FWD_PARTS")) : 0;
@@ -80,6 +90,9 @@ struct hsk_ws {
   // have n_part - 1 extra columns
   int n_part_max;
   long long part_stride;
+  // grouped preparation: slots per set and the distance (in elements) between the slots of a per-batch buffer
+  int group;
+  int64_t gs_batch, gs_ent, gs_items, gs_users;
   // second set of the per-batch buffers: the next batch is sampled and sorted into it while this one trains
   int *u32_b, *it32_b, *perm_b, *hist_b, *btot_b, *bstart_b, *offsets_b, *owner_b, *cnt_b;
   int2* perm1_b;
@@ -87,7 +100,14 @@ struct hsk_ws {
 };
 
 // view with the per-batch buffers of `set` in the primary slots
-static inline hsk_ws hsk_select(const hsk_ws& w, int set) {
+static inline hsk_ws hsk_select(const hsk_ws& w0, int set, int slot = 0) {
+  hsk_ws w = w0;
+  if (slot > 0) {   // slot `slot` of both sets' per-batch buffers (grouped preparation)
+    for (int** p : {&w.u32, &w.u32_b}) *p += slot * w.gs_batch;
+    for (int** p : {&w.it32, &w.it32_b, &w.perm, &w.perm_b}) *p += slot * w.gs_ent;
+    for (int** p : {&w.offsets, &w.offsets_b}) *p += slot * w.gs_items;
+    for (int** p : {&w.owner, &w.owner_b, &w.cnt, &w.cnt_b, &w.stamp, &w.stamp_b}) *p += slot * w.gs_users;
+  }
   if (set == 0) return w;
   hsk_ws r = w;
   std::swap(r.u32, r.u32_b);
@@ -120,17 +140,23 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.part_stride = max_batch * dim;
   const int64_t ent = max_batch * (max_cols + w.n_part_max - 1);   // partitioned rows: the positive n_part times
   const int64_t hist_elems = hsk_sort_hist_elems(n_items, ent);
-  w.u32 = (int*)take(max_batch * 4);
-  w.it32 = (int*)take(ent * 4);
+  const int G = hsk_group_rule(n_items, dim, max_batch, max_cols);
+  w.group = G;
+  w.gs_batch = max_batch;
+  w.gs_ent = ent;
+  w.gs_items = n_items + 1;
+  w.gs_users = n_users;
+  w.u32 = (int*)take(G * max_batch * 4);
+  w.it32 = (int*)take(G * ent * 4);
   w.g_s = (float*)take(ent * 4);
   w.perm1 = (int2*)take(ent * 8);
-  w.perm = (int*)take(ent * 4);
+  w.perm = (int*)take(G * ent * 4);
   w.hist = (int*)take((hist_elems > 0 ? hist_elems : 4) * 4);
   w.btot = (int*)take(HSK_SORT_MAX_BUCKETS * 4);
   w.bstart = (int*)take((HSK_SORT_MAX_BUCKETS + 1) * 4);
-  w.offsets = (int*)take((n_items + 1) * 4);
-  w.owner = (int*)take(n_users * 4);
-  w.cnt = (int*)take(n_users * 4);
+  w.offsets = (int*)take(G * (n_items + 1) * 4);
+  w.owner = (int*)take(G * n_users * 4);
+  w.cnt = (int*)take(G * n_users * 4);
   w.last_step = (int*)take(n_users * 4);
   w.dUb = (float*)take(w.n_part_max * max_batch * dim * 4);
   w.ucur = (float*)take(max_batch * dim * 4);
@@ -142,23 +168,23 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.dupcnt = (int*)take(max_batch * 4);
   w.duplist = (int*)take(max_batch * HSK_DUP_MAX * 4);
   w.last_step_i = (int*)take(n_items * 4);
-  w.stamp = (int*)take(n_users * 4);
-  w.stamp_b = (int*)take(n_users * 4);
+  w.stamp = (int*)take(G * n_users * 4);
+  w.stamp_b = (int*)take(G * n_users * 4);
   w.claim = (int*)take(n_users * 4);
   w.touched = (int*)take(ent * 4);
   w.touched_b = (int*)take(ent * 4);
   w.n_touched = (int*)take(256);
   w.n_touched_b = (int*)take(256);
-  w.u32_b = (int*)take(max_batch * 4);
-  w.it32_b = (int*)take(ent * 4);
+  w.u32_b = (int*)take(G * max_batch * 4);
+  w.it32_b = (int*)take(G * ent * 4);
   w.perm1_b = (int2*)take(ent * 8);
-  w.perm_b = (int*)take(ent * 4);
+  w.perm_b = (int*)take(G * ent * 4);
   w.hist_b = (int*)take((hist_elems > 0 ? hist_elems : 4) * 4);
   w.btot_b = (int*)take(HSK_SORT_MAX_BUCKETS * 4);
   w.bstart_b = (int*)take((HSK_SORT_MAX_BUCKETS + 1) * 4);
-  w.offsets_b = (int*)take((n_items + 1) * 4);
-  w.owner_b = (int*)take(n_users * 4);
-  w.cnt_b = (int*)take(n_users * 4);
+  w.offsets_b = (int*)take(G * (n_items + 1) * 4);
+  w.owner_b = (int*)take(G * n_users * 4);
+  w.cnt_b = (int*)take(G * n_users * 4);
   w.total = off;
   return w;
 }
@@ -223,17 +249,18 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
-  HSK_HIP(hipMemsetAsync(w.cnt, 0, st->n_users * 4, stream));
-  HSK_HIP(hipMemsetAsync(w.cnt_b, 0, st->n_users * 4, stream));
+  const int64_t GU = (int64_t)w.group * st->n_users;   // grouped preparation: G owner maps / stamps per set
+  HSK_HIP(hipMemsetAsync(w.cnt, 0, GU * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.cnt_b, 0, GU * 4, stream));
   HSK_HIP(hipMemsetAsync(w.dupcnt, 0, st->max_batch * 4, stream));
-  HSK_HIP(hipMemsetAsync(w.stamp, 0, st->n_users * 4, stream));
-  HSK_HIP(hipMemsetAsync(w.stamp_b, 0, st->n_users * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.stamp, 0, GU * 4, stream));
+  HSK_HIP(hipMemsetAsync(w.stamp_b, 0, GU * 4, stream));
   HSK_HIP(hipMemsetAsync(w.claim, 0, st->n_users * 4, stream));
   HSK_HIP(hipMemsetAsync(w.n_touched, 0, 4, stream));
   HSK_HIP(hipMemsetAsync(w.n_touched_b, 0, 4, stream));
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_items, 256), 256, 0, stream>>>(w.last_step_i, st->n_items, (int)st->step);
-  k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner, st->n_users, HSK_OWNER_NONE);
-  k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner_b, st->n_users, HSK_OWNER_NONE);
+  k_fill_i32<<<(unsigned)hsk_ceil_div(GU, 256), 256, 0, stream>>>(w.owner, GU, HSK_OWNER_NONE);
+  k_fill_i32<<<(unsigned)hsk_ceil_div(GU, 256), 256, 0, stream>>>(w.owner_b, GU, HSK_OWNER_NONE);
   HSK_LAUNCH_CHECK();
   // rows are current up to the steps already applied (0 for a fresh optimiser)
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.last_step, st->n_users, (int)st->step);
@@ -343,6 +370,8 @@ struct hsk_aux {
   const int64_t* pf_order = nullptr;
   int64_t pf_start = 0, pf_batch = 0, pf_nneg = 0, pf_step = 0;
   int cur_set = 0;  // buffers of the batch of the latest step
+  int cur_slot = 0; // ... and its slot inside the set (grouped preparation; 0 otherwise)
+  bool grouped = false;   // capture of a run with grouped preparation: the steps launch no prefetch of their own
   // graph capture context: while `g_desc` is set the launch sequence is being CAPTURED, not run: kernels take their
   // per-step scalars from the device descriptor + the relative step `g_rel`, launches carry no events of their own
   const hsk_step_desc* g_desc = nullptr;
@@ -641,6 +670,7 @@ static bool hsk_pf_early(int64_t B) {
 static bool hsk_prefetch_wanted(const hsk_bprmf_state* st) {
   hsk_aux* aux = (hsk_aux*)st->aux;
   if (!aux || !aux->hint_valid) return false;
+  if (aux->grouped) return false; // the run's batches are prepared G at a time by the capture loop (hsk_capture_steps)
   if (aux->g_desc) return true;   // inside a graph the fork / join are dependencies, not host calls
   if (aux->hint_batch * (aux->hint_nneg + 1) < HSK_PREFETCH_MIN_ENTRIES) {
     aux->hint_valid = false;  // a few hundred entries: the fork/join events cost more than the five tiny kernels
@@ -679,9 +709,10 @@ static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set
 
 // stages after prep filled u32 / it32 / owner / cnt of `w` (and, with sorted == true, the item sort too)
 // n_part > 1: batch rows in the partitioned layout (the positive in n_part columns) -> item-partitioned forward
+// slot: the batch's slot inside the set (grouped preparation)
 static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool sorted, int64_t B, int64_t K,
-                        hipStream_t stream, int n_part = 1) {
-  const hsk_ws w = hsk_select(w_all, set);
+                        hipStream_t stream, int n_part = 1, int slot = 0) {
+  const hsk_ws w = hsk_select(w_all, set, slot);
   const int64_t K_real = K;
   K = hsk_part_cols(K_real, n_part);   // columns of the batch rows: the positive n_part times (k_prep_sample)
   const int64_t total = B * K;
@@ -692,7 +723,10 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   const float inv_bn = (float)inv_bn_d;
   hsk_aux* aux = (hsk_aux*)st->aux;
   const bool gen = st->opt_kind != HSK_OPT_ADAMW;   // generic optimiser arithmetic instead of the AdamW-only kernels
-  if (aux) aux->cur_set = set;
+  if (aux) {
+    aux->cur_set = set;
+    aux->cur_slot = slot;
+  }
   if (!sorted) {
     int src = hsk_launch_sort(st, w, total, stream);
     if (src) return src;
@@ -1047,7 +1081,7 @@ static int hsk_capture_steps(hsk_bprmf_state* st, const hsk_ws& w, int64_t n, in
       HSK_HIP(hipFuncSetAttribute((const void*)k_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds));
   }
   const int64_t step_saved = st->step;
-  const int set_saved = aux->cur_set;
+  const int set_saved = aux->cur_set, slot_saved = aux->cur_slot;
   const int timing_saved = st->timing_now;
   st->timing_now = 0;
   aux->g_desc = w.desc;
@@ -1059,7 +1093,53 @@ static int hsk_capture_steps(hsk_bprmf_state* st, const hsk_ws& w, int64_t n, in
     return HSK_ERR_HIP;
   }
   int set = set0;
-  for (int64_t s = 0; s < n && rc == HSK_OK; ++s) {
+  // Grouped preparation: the batches of G consecutive steps are sampled and sorted by one launch each -- group 0 on the
+  // main stream at the head of the run, group i+1 on the side stream from the first step of group i on; the steps
+  // themselves launch no prefetch.  (k_sort_lds shapes only: one workgroup per batch.)
+  const int G = (!st->lazy_items && hsk_sort_lds_fits(st->n_items, total)) ? std::min<int64_t>(w.group, n) : 1;
+  auto prepare_group = [&](int gset, int64_t first, hipStream_t q) -> int {
+    const hsk_ws wg = hsk_select(w, gset);
+    const int cnt_g = (int)std::min<int64_t>(G, n - first);
+    k_prep_sample_group<<<(unsigned)hsk_ceil_div((int64_t)cnt_g * batch, 4), 256, 0, q>>>(
+        st->coo_user, st->coo_item, (int)batch, (int)n_neg, st->csr_indptr, st->csr_indices, (int)st->n_items, st->seed,
+        wg.u32, wg.it32, wg.owner, wg.cnt, st->status, hsk_alias{st->alias_prob, st->alias_idx}, w.desc, (int)first,
+        wg.stamp, cnt_g, (long long)w.gs_batch, (long long)w.gs_ent, (long long)w.gs_users);
+    k_sort_lds<<<(unsigned)cnt_g, 1024, hsk_sort_lds_bytes(st->n_items), q>>>(
+        wg.it32, (int)total, (int)st->n_items, wg.perm, wg.offsets, nullptr, nullptr, nullptr, (long long)w.gs_ent,
+        (long long)w.gs_items);
+    return hipGetLastError() == hipSuccess ? HSK_OK : HSK_ERR_HIP;
+  };
+  if (G > 1) {
+    aux->grouped = true;
+    for (int64_t s = 0; s < n && rc == HSK_OK; ++s) {
+      const int64_t gi = s / G;
+      const int slot = (int)(s - gi * G);
+      const int gset = (set0 + (int)gi) & 1;
+      aux->g_rel = (int)s;
+      if (s == 0) rc = prepare_group(gset, 0, stream);
+      if (rc == HSK_OK && slot == 0) {
+        if (s > 0 && hipStreamWaitEvent(stream, aux->ev_ready, 0) != hipSuccess) rc = HSK_ERR_HIP;   // this group is ready
+        if (rc == HSK_OK && (gi + 1) * G < n) {   // the next group: on the side stream from here on
+          if (hipEventRecord(aux->ev_fork, stream) != hipSuccess || hipStreamWaitEvent(aux->side, aux->ev_fork, 0) != hipSuccess)
+            rc = HSK_ERR_HIP;
+          if (rc == HSK_OK) rc = prepare_group(gset ^ 1, (gi + 1) * G, aux->side);
+          if (rc == HSK_OK && hipEventRecord(aux->ev_ready, aux->side) != hipSuccess) rc = HSK_ERR_HIP;
+        }
+      }
+      if (rc == HSK_OK && s + 1 < n) {   // names the next batch for the ahead-of-time user catch-up (no prefetch: grouped)
+        aux->hint_valid = true;
+        aux->hint_order = nullptr;
+        aux->hint_start = 0;
+        aux->hint_batch = batch;
+        aux->hint_nneg = n_neg;
+      } else {
+        aux->hint_valid = false;
+      }
+      if (rc == HSK_OK) rc = hsk_run_step(st, w, gset, true, batch, K, stream, 1, slot);
+    }
+    aux->grouped = false;
+  }
+  for (int64_t s = 0; s < n && rc == HSK_OK && G <= 1; ++s) {
     aux->g_rel = (int)s;
     bool sorted = true;
     if (s == 0) {   // the run's first batch is prepared inside the graph, on the main stream
@@ -1087,6 +1167,7 @@ static int hsk_capture_steps(hsk_bprmf_state* st, const hsk_ws& w, int64_t n, in
   aux->hint_valid = false;
   aux->pf_valid = false;
   aux->cur_set = set_saved;
+  aux->cur_slot = slot_saved;
   st->step = step_saved;
   st->timing_now = timing_saved;
   if (rc == HSK_OK && e != hipSuccess) {
@@ -1144,7 +1225,16 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
       HSK_HIP(hipGraphLaunch(exec, stream));
       aux->graph_launches += 1;
       st->step += n;
-      aux->cur_set = (n & 1) ? set0 : (set0 ^ 1);
+      {
+        const int Gr = (!st->lazy_items && hsk_sort_lds_fits(st->n_items, batch * (n_neg + 1))) ? (int)std::min<int64_t>(w.group, n) : 1;
+        if (Gr > 1) {   // grouped preparation: the last batch sits in slot (n-1) % G of set (set0 + (n-1)/G) & 1
+          aux->cur_set = (set0 + (int)((n - 1) / Gr)) & 1;
+          aux->cur_slot = (int)((n - 1) % Gr);
+        } else {
+          aux->cur_set = (n & 1) ? set0 : (set0 ^ 1);
+          aux->cur_slot = 0;
+        }
+      }
       s += n;
       // lazily updated rows: the periodic sweep that bounds the replay length closes every replayed run (the eager
       // path sweeps at multiples of HSK_FLUSH_EVERY; the cadence is a speed matter, any replay length is exact)
@@ -1189,7 +1279,7 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   if ((rc = hsk_check_batch(st, batch, n_cols))) return rc;
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   const int64_t total = batch * n_cols;
-  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set);
+  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set, ((hsk_aux*)st->aux)->cur_slot);
   // partitioned row layout: the positive sits in n_part columns, the caller sees it once
   const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0);
   k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
@@ -1210,7 +1300,7 @@ extern "C" int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries,
   HSK_REQUIRE(perm_out && offsets_out && n_entries > 0 && n_entries <= st->max_batch * (st->max_cols + HSK_PART_MAX - 1),
               HSK_ERR_INVALID, "bad argument");
   hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
-  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set);
+  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set, ((hsk_aux*)st->aux)->cur_slot);
   HSK_HIP(hipMemcpyAsync(perm_out, w.perm, n_entries * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
   HSK_HIP(hipMemcpyAsync(offsets_out, w.offsets, (st->n_items + 1) * sizeof(int), hipMemcpyDeviceToDevice,
                          (hipStream_t)stream_));

@@ -109,33 +109,15 @@ __device__ __forceinline__ int hsk_draw_negative(const int32_t* __restrict__ csr
   return last;
 }
 
-// one wave per positive; lanes stride over the n_neg slots
-__global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__ coo_user,
+// one wave per positive (b = its batch position); lanes stride over the n_neg slots
+__device__ __forceinline__ void hsk_prep_sample_body(int b, int lane, int wave, const int32_t* __restrict__ coo_user,
                                                      const int32_t* __restrict__ coo_item,
-                                                     const int64_t* __restrict__ order, long long start, int B,
-                                                     int n_neg, const int64_t* __restrict__ csr_indptr,
-                                                     const int32_t* __restrict__ csr_indices, int n_items,
-                                                     uint64_t seed, uint64_t stream_id, int* __restrict__ u32,
-                                                     int* __restrict__ it32,
-                                                     int* __restrict__ owner, int* __restrict__ cnt,
-                                                     int32_t* status, int b_offset = 0,
-                                                     hsk_alias at = hsk_alias{nullptr, nullptr},
-                                                     const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0,
-                                                     int* __restrict__ stamp = nullptr, int n_part = 1) {
-  // n_part > 1: rows of K + n_part - 1 columns, the positive in column 0, -1 in columns 1 .. n_part-1 (see k_prep_external)
-  // stamp (optional): stamp[u] = the (1-based) step this batch is trained on, for every user of the batch -- how a
-  // kernel of that step tells the rows being updated from the rows it may bring up to date ahead of time
-  // b_offset: offset added to the batch position in the RNG counter (a slice of a larger global batch).
-  // owner == NULL: no owner map.  desc: graph replay, see hsk_step_desc.
-  if (desc) {
-    start = desc->start0 + (long long)rel * B;
-    order = desc->order;
-    stream_id = (uint64_t)(desc->step0 + rel);
-  }
-  const int lane = hsk_lane();
-  const int wave = hsk_uniform_i(threadIdx.x >> 6);
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
+                                                     const int64_t* __restrict__ order, long long start, int n_neg,
+                                                     const int64_t* __restrict__ csr_indptr,
+                                                     const int32_t* __restrict__ csr_indices, int n_items, uint64_t seed,
+                                                     uint64_t stream_id, int* __restrict__ u32, int* __restrict__ it32,
+                                                     int* __restrict__ owner, int* __restrict__ cnt, int32_t* status,
+                                                     int b_offset, hsk_alias at, int* __restrict__ stamp, int n_part) {
   const long long pos = order ? (long long)order[start + b] : (start + b);
   const int u = coo_user[pos];
   const int ipos = coo_item[pos];
@@ -166,6 +148,59 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
     }
     if (stamp) stamp[u] = (int)stream_id + 1;
   }
+}
+
+__global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__ coo_user,
+                                                     const int32_t* __restrict__ coo_item,
+                                                     const int64_t* __restrict__ order, long long start, int B,
+                                                     int n_neg, const int64_t* __restrict__ csr_indptr,
+                                                     const int32_t* __restrict__ csr_indices, int n_items,
+                                                     uint64_t seed, uint64_t stream_id, int* __restrict__ u32,
+                                                     int* __restrict__ it32,
+                                                     int* __restrict__ owner, int* __restrict__ cnt,
+                                                     int32_t* status, int b_offset = 0,
+                                                     hsk_alias at = hsk_alias{nullptr, nullptr},
+                                                     const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0,
+                                                     int* __restrict__ stamp = nullptr, int n_part = 1) {
+  // n_part > 1: rows of K + n_part - 1 columns, the positive in column 0, -1 in columns 1 .. n_part-1 (see k_prep_external)
+  // stamp (optional): stamp[u] = the (1-based) step this batch is trained on, for every user of the batch -- how a
+  // kernel of that step tells the rows being updated from the rows it may bring up to date ahead of time
+  // b_offset: offset added to the batch position in the RNG counter (a slice of a larger global batch).
+  // owner == NULL: no owner map.  desc: graph replay, see hsk_step_desc.
+  if (desc) {
+    start = desc->start0 + (long long)rel * B;
+    order = desc->order;
+    stream_id = (uint64_t)(desc->step0 + rel);
+  }
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  hsk_prep_sample_body(b, lane, wave, coo_user, coo_item, order, start, n_neg, csr_indptr, csr_indices, n_items, seed,
+                       stream_id, u32, it32, owner, cnt, status, b_offset, at, stamp, n_part);
+}
+
+// The batches of n_group consecutive steps of a replayed run in ONE launch (graph replay only: step / start / order come
+// from the descriptor): batch g = relative step rel0 + g, written to slot g of the per-batch buffers (gs_* = distance
+// between the slots, in elements).  Same draws as n_group launches of k_prep_sample.
+__global__ __launch_bounds__(256) void k_prep_sample_group(const int32_t* __restrict__ coo_user,
+                                                           const int32_t* __restrict__ coo_item, int B, int n_neg,
+                                                           const int64_t* __restrict__ csr_indptr,
+                                                           const int32_t* __restrict__ csr_indices, int n_items,
+                                                           uint64_t seed, int* __restrict__ u32, int* __restrict__ it32,
+                                                           int* __restrict__ owner, int* __restrict__ cnt, int32_t* status,
+                                                           hsk_alias at, const hsk_step_desc* __restrict__ desc, int rel0,
+                                                           int* __restrict__ stamp, int n_group, long long gs_batch,
+                                                           long long gs_ent, long long gs_users) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int bb = blockIdx.x * 4 + wave;
+  const int g = bb / B, b = bb - g * B;
+  if (g >= n_group) return;
+  const int rel = rel0 + g;
+  hsk_prep_sample_body(b, lane, wave, coo_user, coo_item, desc->order, desc->start0 + (long long)rel * B, n_neg, csr_indptr,
+                       csr_indices, n_items, seed, (uint64_t)(desc->step0 + rel), u32 + g * gs_batch, it32 + g * gs_ent,
+                       owner + g * gs_users, cnt + g * gs_users, status, 0, at, stamp + g * gs_users, 1);
 }
 
 // stand-alone sampler on the int64 drop-in surface

@@ -377,7 +377,12 @@ __global__ __launch_bounds__(1024) void k_sort_lds(const int* __restrict__ it32,
                                                    int* __restrict__ perm, int* __restrict__ offsets,
                                                    int* __restrict__ touched = nullptr,
                                                    int* __restrict__ n_touched = nullptr,
-                                                   const int* __restrict__ n_dev = nullptr) {
+                                                   const int* __restrict__ n_dev = nullptr, long long gs_ent = 0,
+                                                   long long gs_items = 0) {
+  // grouped preparation: workgroup g sorts the batch in slot g of the per-batch buffers (one workgroup: g = 0)
+  it32 += blockIdx.x * gs_ent;
+  perm += blockIdx.x * gs_ent;
+  offsets += blockIdx.x * gs_items;
   n_entries = hsk_sort_count(n_entries, n_dev);
   extern __shared__ int lds[];
   const int I = n_items;
