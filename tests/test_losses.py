@@ -168,3 +168,34 @@ def test_fused_losses_vs_oracle_at_baseline_shape(oracle, kind):
     st.flush()
     for name in P:
         assert_adam_param_close(t[name].cpu().numpy(), tr.P[name], name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,optimizer', [('bpr', 'adamw'), ('bce', 'adamw'), ('bpr', 'adagrad')])
+def test_item_partitioned_forward_vs_oracle(oracle, kind, optimizer):
+    """A shape that selects the item-partitioned forward (csrc/hsk_fwd_part.h: B = 2048, D = 256, a 6.1 MB item table ->
+    P = 2) on loader-supplied batches with repeated users: three steps (the second and third find lazily updated rows
+    behind, i.e. every unit replays them) against the CPU oracle -- loss to 2e-6, parameters by the Adam rule."""
+    from hassaku_amd import hip_ops as ops
+    rng = np.random.RandomState(9)
+    U, I, D, B, N = 40000, 6000, 256, 2048, 16
+    P = {'user_emb': (rng.randn(U, D) * 0.08).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.08).astype(np.float32),
+         'item_bias': (rng.randn(I) * 0.1).astype(np.float32)}
+    t = {k: dev(v) for k, v in P.items()}
+    st = ops.BprMfFusedState(t['user_emb'], t['item_emb'], t['item_bias'], lr=3e-4, wd=4e-5, max_batch=B, max_cols=N + 1,
+                             loss=kind, optimizer=optimizer)
+    assert st.batch_columns(B, N + 1) == N + 2, 'this shape is meant to run the partitioned forward with P = 2'
+    tr = oracle.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], lr=3e-4, wd=4e-5, loss=kind,
+                                optimizer=optimizer)
+    for _ in range(3):
+        u = rng.randint(0, U, size=B).astype(np.int64)
+        u[rng.rand(B) < 0.05] = u[0]                      # one user many times, others twice now and then
+        i = rng.randint(0, I, size=(B, N + 1)).astype(np.int64)
+        st.step(dev(u), dev(i))
+        ref, _, _, _ = tr.step(u, i)
+        assert abs(st.last_loss() - ref) <= 2e-6 * abs(ref)
+    st.flush()
+    st.check_status()
+    tol = dict(max_tol=5e-3, frac=5e-3) if optimizer == 'adagrad' else {}
+    for name in P:
+        assert_adam_param_close(t[name].cpu().numpy(), tr.P[name], name, **tol)
