@@ -55,7 +55,7 @@ ICACHE_GATHER_GBS = 8600.0   # same guide, "Indexed rows": uniformly random rows
 L2_GATHER_GBS = 17800.0      # same table: rows shared by every workgroup of an XCD (its L2), 16.8-18.8 TB/s chip-wide
 HBM_GATHER_GBS = 5750.0      # same guide: random 2.3 KB rows of a table far beyond the Infinity Cache, 5.7-5.8 TB/s
 MFMA_FP32_TFLOPS = 157.0     # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32; no xf32 on gfx950)
-PROFILE_DIR = {'ml10m': 'r2b_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2_ml1m', 'ml100k': 'r2_ml100k'}  # committed rocprofv3 summaries
+PROFILE_DIR = {'ml10m': 'r2b_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2b_ml1m', 'ml100k': 'r2b_ml100k'}  # committed rocprofv3 summaries
 LR, WD = 3e-4, 4e-5          # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
