@@ -869,7 +869,10 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
                           (unsigned)(NW * (size_t)D * sizeof(float)), stream, fwd_beg, fwd_end, 0,                   \
                           (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,      \
                           (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b, lz)
-    const bool wg_fwd = B <= 1024 && st->loss_kind != HSK_LOSS_SSM && K >= 9;
+    // (also for very few columns: idle waves of the workgroup cost nothing at B = 128 and the kernel's loads come in two
+    // rounds instead of four -- ml100k shape, K = 2: 13.8 -> 12.2 us per step; HSK_WG_MINK=9 restores the old rule)
+    static const int wg_min_k = getenv("HSK_WG_MINK") ? atoi(getenv("HSK_WG_MINK")) : 2;
+    const bool wg_fwd = B <= 1024 && st->loss_kind != HSK_LOSS_SSM && K >= wg_min_k;
     const bool wg8 = wg_fwd && K >= 33 && B <= 256;   // few, wide positives: 8 waves each
     if (wg_fwd && st->loss_kind == HSK_LOSS_BCE) {
       if (wg8) { HSK_LAUNCH_FWD_WG(HSK_LOSS_BCE, 8); } else { HSK_LAUNCH_FWD_WG(HSK_LOSS_BCE, 4); }

@@ -30,34 +30,48 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_ugrad_wg(const float* __restric
 
   using Row = hsk_row<V, NCH>;
   const int* __restrict__ irow = it32 + (long long)b * K;
-  const int u = hsk_uniform_i(u32[b]);
-  const int i0 = hsk_uniform_i(irow[0]);
+  // Loads in two rounds, not a chain of four (a small step is a chain of latencies): (1) what depends on b only -- user
+  // id, positive, this wave's first 64 item ids; (2) user row, positive's row, lazy-update state, biases, first item rows.
+  const int per = (K - 1 + NW - 1) / NW;           // columns per wave
+  const int k_lo = 1 + sub * per, k_hi = min(K, k_lo + per);
+  int kc = k_lo;
+  int nr = max(0, min(64, k_hi - kc));
+  const int u_v = u32[b];
+  const int i0_v = irow[0];
+  const int id_v = (lane < nr) ? irow[kc + lane] : -1;
+  const int u = hsk_uniform_i(u_v);
+  const int i0 = hsk_uniform_i(i0_v);
+  int myidx = (lane < nr) ? id_v : i0;
   Row ur, r0, acc;
   hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
   hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  int done_v = 0, own_v = 0;
+  if (lz.mU) {
+    done_v = lz.last_step[u];
+    own_v = lz.owner[u];
+  }
+  const float bias0 = Ib ? Ib[i0] : 0.f;
+  float mybias = Ib ? Ib[myidx] : 0.f;
+  Row bufA[R], bufB[R];
+  auto prefetch = [&](Row(&buf)[R], int j) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (j + r < nr) hsk_row_load<V, NCH, FULL>(buf[r], Iw + (long long)hsk_readlane_i(myidx, j + r) * D, lane, D);
+  };
+  prefetch(bufA, 0);
   // lazily updated user row: every wave replays the pending steps on its own copy (identical results), wave 0
   // publishes the current row for the item pass
   if (lz.mU)
-    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, sub == 0, hsk_uniform_i(lz.last_step[u]),
-                                       hsk_uniform_i(lz.owner[u]));
+    hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, sub == 0, hsk_uniform_i(done_v), hsk_uniform_i(own_v));
   else if (lz.ucur && sub == 0)
     hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
   hsk_row_zero(acc);
-  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
+  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + bias0;
 
-  const int per = (K - 1 + NW - 1) / NW;           // columns per wave
-  const int k_lo = 1 + sub * per, k_hi = min(K, k_lo + per);
   float gsum = 0.f;
   double lsum = 0.0;
-  for (int kc = k_lo; kc < k_hi; kc += 64) {
-    const int nr = min(64, k_hi - kc);
-    const int myidx = (lane < nr) ? irow[kc + lane] : i0;
-    const float mybias = Ib ? Ib[myidx] : 0.f;
+  while (nr > 0) {
     float gv = 0.f, xv = 0.f;
-    Row bufA[R], bufB[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (r < nr) hsk_row_load<V, NCH, FULL>(bufA[r], Iw + (long long)hsk_readlane_i(myidx, r) * D, lane, D);
     auto process = [&](Row(&buf)[R], int j) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -78,11 +92,6 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_ugrad_wg(const float* __restric
         }
       }
     };
-    auto prefetch = [&](Row(&buf)[R], int j) {
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (j + r < nr) hsk_row_load<V, NCH, FULL>(buf[r], Iw + (long long)hsk_readlane_i(myidx, j + r) * D, lane, D);
-    };
     for (int j = 0; j < nr; j += 2 * R) {
       prefetch(bufB, j + R);
       process(bufA, j);
@@ -93,6 +102,12 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_ugrad_wg(const float* __restric
       g_s[(long long)b * K + kc + lane] = gv;
       lsum += (double)(LOSS == HSK_LOSS_BPR ? hsk_softplus(-xv) : hsk_softplus(xv));
     }
+    kc += 64;
+    nr = max(0, min(64, k_hi - kc));
+    if (nr == 0) break;
+    myidx = (lane < nr) ? irow[kc + lane] : i0;
+    mybias = Ib ? Ib[myidx] : 0.f;
+    prefetch(bufA, 0);
   }
 
   // combine: waves 1..3 park their partial row / sums in LDS, wave 0 adds them in wave order
