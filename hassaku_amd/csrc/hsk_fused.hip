@@ -86,10 +86,9 @@ struct hsk_ws {
   int *stamp, *stamp_b;    // per buffer set: stamp[u] = step the set's batch is trained on (for its users)
   int* claim;              // ahead-of-time catch-up: last step at which a row was claimed
   int *touched, *n_touched, *touched_b, *n_touched_b;   // per buffer set: items with entries (compact), their count
-  // item-partitioned forward: dUb / loss_b hold n_part_max partial planes (part_stride floats apart); the batch rows
+  // item-partitioned forward: dUb holds n_part_max partial rows per batch position, loss_b as many planes; the batch rows
   // have n_part - 1 extra columns
   int n_part_max;
-  long long part_stride;
   // grouped preparation: slots per set and the distance (in elements) between the slots of a per-batch buffer
   int group;
   int64_t gs_batch, gs_ent, gs_items, gs_users;
@@ -137,7 +136,6 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
     return r;
   };
   w.n_part_max = hsk_part_rule(n_items, dim, max_batch, std::min<int64_t>(max_cols - 1, 256), false);   // an upper bound
-  w.part_stride = max_batch * dim;
   const int64_t ent = max_batch * (max_cols + w.n_part_max - 1);   // partitioned rows: the positive n_part times
   const int64_t hist_elems = hsk_sort_hist_elems(n_items, ent);
   const int G = hsk_group_rule(n_items, dim, max_batch, max_cols);
@@ -525,7 +523,6 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
     const int stride = n_ahead_oct ? item_oct / n_ahead_oct : 0;
     const int nab_big = ahead.coo_user ? (int)hsk_align_up(hsk_ceil_div(ahead.n, 4), 8) : 0;   // large-batch kernel
 
-    static const int user_last = getenv("HSK_USER_LAST") ? atoi(getenv("HSK_USER_LAST")) : 0;
 #define HSK_ITEM_USER(VS, GEN, LZ)                                                                             \
   do {                                                                                                         \
     if (whole_rows)                                                                                            \
@@ -533,8 +530,8 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
           ia, *ua, nub, dense, ahead, n_ahead_oct, stride);                                                    \
     else if (part) {                                                                                           \
       if constexpr (V == 4 && FULL && !LZ)                                                                      \
-        k_item_user<V, NCH, FULL, VS, GEN, LZ, true><<<nblk + (unsigned)nub, 256, 0, stream>>>(                   \
-            ia, *ua, nub, dense, ahead, user_last ? -(int)nblk : 0);                                            \
+        k_item_user<V, NCH, FULL, VS, GEN, LZ, true><<<nblk + (unsigned)nub, 256, 0, stream>>>(ia, *ua, nub, dense, \
+                                                                                            ahead, 0);         \
     } else                                                                                                     \
       k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)(nub + (LZ ? nab_big : 0)), 256, 0, stream>>>(   \
           ia, *ua, nub, dense, ahead, LZ ? nab_big : 0);                                                       \
@@ -831,7 +828,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
         // HSK_AHEAD_MIX=1: the ahead octets interleaved with the unit octets instead of leading (measured: 88 vs 86 us)
         static const int ahead_mix = getenv("HSK_AHEAD_MIX") ? atoi(getenv("HSK_AHEAD_MIX")) : 0;
         const int stride = (ahead_mix && n_ahead > 0) ? (int)(n_unit / 8) / (n_ahead / 8) : 0;
-        const hsk_part_args pa = {n_part, (int)st->n_items, w.part_stride, n_ahead, stride};
+        const hsk_part_args pa = {n_part, (int)st->n_items, n_ahead, stride};
         const unsigned grid = (unsigned)n_ahead + n_unit;
 #define HSK_LAUNCH_FWD_PART(LK, GEN)                                                                                 \
   if (capturing)                                                                                                    \
@@ -912,7 +909,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
                                    st->v_user_bias, w.dUb, w.u32, w.owner, w.cnt, w.last_step, (int)B, D,
                                    (int)st->step, c, fin, w.dupcnt, w.duplist, lazy ? w.adam_tab : nullptr,
                                    HSK_ADAM_TAB_LEN, w.ucur, w.mcur, w.vcur, lazy ? 0 : U, gdesc, grel, w.adam_tab,
-                                   HSK_ADAM_TAB_LEN, n_part, w.part_stride};
+                                   HSK_ADAM_TAB_LEN, n_part};
     const bool timed_apart = st->timing && st->timing_now &&
                              (((st->timing_mask >> HSK_STAGE_ITEM) | (st->timing_mask >> HSK_STAGE_USER)) & 1);
     if (D % 2 == 0 && !timed_apart) {

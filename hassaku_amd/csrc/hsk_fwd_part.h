@@ -26,7 +26,6 @@
 struct hsk_part_args {
   int n_part;                    // P: 2, 4 or 8; partition q = items [ceil(q I / P), ceil((q + 1) I / P))
   int n_items;
-  long long part_stride;         // (unused: the partial rows of a batch position lie side by side, [b][q][D])
   int n_ahead_blocks;            // workgroups that run hsk_user_ahead_body (a multiple of 8)
   int ahead_stride;              // > 0: one OCTET of ahead workgroups follows every `ahead_stride` octets of unit
                                  // workgroups (octets: a unit workgroup keeps blockIdx % 8 == its own index % 8), the

@@ -268,15 +268,7 @@ template <int V, int NCH, bool FULL, int VS, bool GEN, bool LAZYI, bool PART = f
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int dense_users, hsk_ahead_args aa,
                  int n_ahead_blocks) {
-  int bid = (int)blockIdx.x;
-  if (PART && n_ahead_blocks < 0) {   // PART: -n_ahead_blocks item workgroups first, the user workgroups behind them
-    if (bid < -n_ahead_blocks) {
-      hsk_item_sliced_body<true, VS, GEN, LAZYI, PART>(ia, bid);
-      return;
-    }
-    bid -= -n_ahead_blocks;
-    n_ahead_blocks = 0;
-  }
+  const int bid = (int)blockIdx.x;
   if (bid < n_user_blocks) {
     if (dense_users)
       hsk_user_update_dense_body<V, NCH, FULL, GEN, PART>(ua, bid);

@@ -631,8 +631,8 @@ struct hsk_user_lazy_args {
   int n_users;            // dense sweep (hsk_user_update_dense_body): rows of the table
   const hsk_step_desc* desc; int rel;   // graph replay: step = desc->step0 + rel + 1, c from ctab
   const float2* ctab; int ctab_len;
-  int n_part; long long part_stride;   // item-partitioned forward: a gradient row is the sum of n_part partial rows,
-                                       // laid out [b][q][D] (the n_part rows of a batch position side by side)
+  int n_part;   // item-partitioned forward: a gradient row is the sum of n_part partial rows, laid out [b][q][D]
+                // (the n_part rows of a batch position side by side)
 };
 
 // gradient chunk of batch position b: the partial rows added in partition order
