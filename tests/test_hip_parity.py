@@ -851,3 +851,34 @@ def test_full_size_fused_step_equals_unfused_operator_chain(ops, oracle):
         assert_adam_param_close(P[name].cpu().numpy(), tr.P[name], 'oracle ' + name)
         assert max_norm_err(st.m[name].cpu().numpy(), tr.M[name]) < 1e-5, name
         assert max_norm_err(st.v[name].cpu().numpy(), tr.V[name]) < 1e-5, name
+
+
+def test_last_batch_after_a_replayed_run_with_grouped_preparation(ops):
+    """After a run of 64 replayed steps whose batches were prepared 8 at a time (k_prep_sample_group), last_batch /
+    last_sort still show the batch of the final step -- the one an eager run of the same steps ends on."""
+    rng = np.random.RandomState(12)
+    n_users, n_items, D, B, N = 200, 500, 64, 128, 3
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.15)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32)}
+    order = torch.from_numpy(np.random.RandomState(3).permutation(len(pairs))).cuda()
+    assert order.numel() >= 64 * B
+    out = []
+    for chunked in (False, True):
+        st, _ = _fused_state(ops, P, 1e-3, 0.0, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                             coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+        if chunked:
+            st.steps_sampled(order, 0, 64, B, N)
+            assert st.graph_replays() == 1
+        else:
+            for s in range(64):
+                st.step_sampled(order, s * B, B, N)
+        u, i = st.last_batch(B, N + 1)
+        perm, offs = st.last_sort(B * (N + 1))
+        out.append([x.cpu().numpy() for x in (u, i, perm, offs)])
+        st.check_status()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[0][0], pairs[order[63 * B:64 * B].cpu().numpy(), 0])
