@@ -882,3 +882,38 @@ def test_last_batch_after_a_replayed_run_with_grouped_preparation(ops):
     for a, b in zip(*out):
         assert np.array_equal(a, b)
     assert np.array_equal(out[0][0], pairs[order[63 * B:64 * B].cpu().numpy(), 0])
+
+
+def test_eval_cfg4_shape_eight_item_shards_vs_float64(ops):
+    """BASELINE configs[3] at its own size on one device: D = 512, 131 072 items cut into the 8 range shards an 8-GPU
+    node holds (physical shards, global ids, exclusion mask restricted to the range, top-k selected inside the GEMM),
+    hsk_topk_merge -> per user the same top-100 as a float64 scoring of the whole catalogue (ids exact wherever the
+    float64 scores are further apart than fp32 can resolve, values to 1e-5)."""
+    torch.manual_seed(1)
+    n_users, n_items, D, k, W = 256, 131072, 512, 100, 8
+    U = torch.randn(n_users, D, device='cuda') * 0.05
+    I = torch.randn(n_items, D, device='cuda') * 0.05
+    Ib = torch.randn(n_items, device='cuda') * 0.1
+    rng = np.random.RandomState(8)
+    e_ptr, e_idx = _toy_csr(rng, n_users, n_items, 120.0 / n_items)
+    u = torch.arange(n_users, device='cuda')
+    parts_v, parts_i = [], []
+    for r in range(W):
+        lo, hi = n_items * r // W, n_items * (r + 1) // W
+        v, i, sc = ops.mf_eval_topk(U, I[lo:hi].contiguous(), Ib[lo:hi].contiguous(), None, None, u, k, dev(e_ptr), dev(e_idx),
+                                    item_begin=lo, item_count=hi - lo, item_shard=True, n_items_global=n_items,
+                                    want_scores=(r % 2 == 1))   # even shards: selection inside the GEMM; odd: materialised
+        assert (sc is None) == (r % 2 == 0)
+        parts_v.append(v)
+        parts_i.append(i)
+    mv, mi = ops.topk_merge(torch.stack(parts_v).contiguous(), torch.stack(parts_i).contiguous())
+    ref = U.double() @ I.double().T + Ib.double()[None, :]
+    ptr, idx = e_ptr, e_idx
+    for r in range(n_users):
+        ref[r, torch.from_numpy(idx[ptr[r]:ptr[r + 1]].astype(np.int64)).cuda()] = float('-inf')
+    rv, ri = torch.topk(ref, k + 1, dim=1)
+    assert torch.allclose(mv.double(), rv[:, :k], rtol=1e-5, atol=1e-6)
+    gap = (rv[:, :-1] - rv[:, 1:]) > 1e-5            # ranks whose neighbours are clearly apart
+    clear = gap & torch.cat([torch.ones_like(gap[:, :1]), gap[:, :-1]], dim=1)
+    assert clear.float().mean() > 0.9
+    assert torch.equal(mi.long()[clear], ri[:, :k][clear])
