@@ -22,6 +22,22 @@ __device__ __forceinline__ hsk_adamw_consts hsk_consts_at(const hsk_adamw_consts
 }
 
 
+// The per-step scalars of up to 64 consecutive steps t0 .. t0+63 in ONE vector load (lane j: step t0 + j), handed out by
+// readlane: a table load per replayed step puts a memory latency into every iteration of the serial replay chain.
+__device__ __forceinline__ float2 hsk_consts_block(const float2* __restrict__ tab, int tab_len, int t0) {
+  return tab[min(t0 + hsk_lane(), tab_len)];
+}
+__device__ __forceinline__ hsk_adamw_consts hsk_consts_lane(const hsk_adamw_consts& base, float2 block, int j) {
+  hsk_adamw_consts c = base;
+  c.step_size = hsk_readlane_f(block.x, j);
+#if HSK_ADAM_IEEE
+  c.bc2_sqrt = hsk_readlane_f(block.y, j);
+#else
+  c.rbc2_sqrt = hsk_readlane_f(block.y, j);
+#endif
+  return c;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Lazy user rows inside the forward.  A user row outside the previous batches carries pending zero-gradient AdamW
 // steps (see "Lazy, exact user-table AdamW" below).  Instead of a separate catch-up launch that rewrites the row
@@ -62,18 +78,22 @@ __device__ __forceinline__ void hsk_user_row_current(hsk_row<V, NCH>& p, int u, 
     hsk_row<V, NCH> m, v;
     hsk_row_load<V, NCH, FULL>(m, lz.mU + (long long)u * D, lane, D);
     hsk_row_load<V, NCH, FULL>(v, lz.vU + (long long)u * D, lane, D);
-    for (int t = done + 1; t <= step - 1; ++t) {
-      const hsk_adamw_consts ct = hsk_consts_at(lz.c, lz.tab, lz.tab_len, t);
-      if (lz.gen) {
+    for (int t0 = done + 1; t0 <= step - 1; t0 += 64) {
+      const float2 blk = hsk_consts_block(lz.tab, lz.tab_len, t0);
+      const int nt = min(64, step - t0);
+      for (int j = 0; j < nt; ++j) {
+        const hsk_adamw_consts ct = hsk_consts_lane(lz.c, blk, j);
+        if (lz.gen) {
 #pragma unroll
-        for (int cc = 0; cc < NCH; ++cc)
+          for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
-          for (int q = 0; q < V; ++q) hsk_adamw_replay<true>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
-      } else {
+            for (int q = 0; q < V; ++q) hsk_adamw_replay<true>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+        } else {
 #pragma unroll
-        for (int cc = 0; cc < NCH; ++cc)
+          for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
-          for (int q = 0; q < V; ++q) hsk_adamw_replay<false>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+            for (int q = 0; q < V; ++q) hsk_adamw_replay<false>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+        }
       }
     }
     if (publish && own == b) {
@@ -458,25 +478,38 @@ __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, floa
                                                   float* __restrict__ vrow, int D, int from, int to,
                                                   const hsk_adamw_consts& base, const float2* __restrict__ tab,
                                                   int tab_len) {
-  for (int d0 = threadIdx.x * VV; d0 < D; d0 += 256 * VV) {
-    hsk_vec<VV> p = hsk_ldg<VV>(prow + d0), m = hsk_ldg<VV>(mrow + d0), v = hsk_ldg<VV>(vrow + d0);
-    for (int t = from + 1; t <= to; ++t) {
-      const hsk_adamw_consts c = hsk_consts_at(base, tab, tab_len, t);
-#pragma unroll
-      for (int q = 0; q < VV; ++q) hsk_adamw_replay<GEN>(p.v[q], m.v[q], v.v[q], c);
+  for (int db = 0; db < D; db += 256 * VV) {   // uniform trip count: every lane takes part in the scalar hand-out below
+    const int d0 = db + threadIdx.x * VV;
+    const bool live = d0 < D;
+    hsk_vec<VV> p = hsk_zero<VV>(), m = hsk_zero<VV>(), v = hsk_zero<VV>();
+    if (live) {
+      p = hsk_ldg<VV>(prow + d0);
+      m = hsk_ldg<VV>(mrow + d0);
+      v = hsk_ldg<VV>(vrow + d0);
     }
+    for (int t0 = from + 1; t0 <= to; t0 += 64) {
+      const float2 blk = hsk_consts_block(tab, tab_len, t0);
+      const int nt = min(64, to - t0 + 1);
+      for (int j = 0; j < nt; ++j) {
+        const hsk_adamw_consts c = hsk_consts_lane(base, blk, j);
+#pragma unroll
+        for (int q = 0; q < VV; ++q) hsk_adamw_replay<GEN>(p.v[q], m.v[q], v.v[q], c);
+      }
+    }
+    if (live) {
 #if HSK_REPLAY_NT > 1
-    hsk_stg_nt<VV>(prow + d0, p);
+      hsk_stg_nt<VV>(prow + d0, p);
 #else
-    hsk_stg<VV>(prow + d0, p);
+      hsk_stg<VV>(prow + d0, p);
 #endif
 #if HSK_REPLAY_NT
-    hsk_stg_nt<VV>(mrow + d0, m);
-    hsk_stg_nt<VV>(vrow + d0, v);
+      hsk_stg_nt<VV>(mrow + d0, m);
+      hsk_stg_nt<VV>(vrow + d0, v);
 #else
-    hsk_stg<VV>(mrow + d0, m);
-    hsk_stg<VV>(vrow + d0, v);
+      hsk_stg<VV>(mrow + d0, m);
+      hsk_stg<VV>(vrow + d0, v);
 #endif
+    }
   }
 }
 
@@ -516,12 +549,17 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
     return;
   }
   if (done >= step - 1) return;
-  if (d0 < D) {   // first pass of the replay on the preloaded elements
-    for (int t = done + 1; t <= step - 1; ++t) {
-      const hsk_adamw_consts ct = hsk_consts_at(c, tab, tab_len, t);
+  // first pass of the replay on the preloaded elements (every lane walks the steps: the scalars come by readlane)
+  for (int t0 = done + 1; t0 <= step - 1; t0 += 64) {
+    const float2 blk = hsk_consts_block(tab, tab_len, t0);
+    const int nt = min(64, step - t0);
+    for (int j = 0; j < nt; ++j) {
+      const hsk_adamw_consts ct = hsk_consts_lane(c, blk, j);
 #pragma unroll
       for (int q = 0; q < VV; ++q) hsk_adamw_replay<GEN>(p0.v[q], m0.v[q], v0.v[q], ct);
     }
+  }
+  if (d0 < D) {
     hsk_stg<VV>(prow + d0, p0);
     hsk_stg<VV>(mrow + d0, m0);
     hsk_stg<VV>(vrow + d0, v0);
@@ -888,12 +926,16 @@ __device__ __forceinline__ void hsk_user_ahead_body(const hsk_ahead_args& a, int
   hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
   hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
   hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
-  for (int t = done + 1; t <= step; ++t) {
-    const hsk_adamw_consts ct = hsk_consts_at(a.c, a.tab, a.tab_len, t);
+  for (int t0 = done + 1; t0 <= step; t0 += 64) {
+    const float2 blk = hsk_consts_block(a.tab, a.tab_len, t0);
+    const int nt = min(64, step - t0 + 1);
+    for (int j = 0; j < nt; ++j) {
+      const hsk_adamw_consts ct = hsk_consts_lane(a.c, blk, j);
 #pragma unroll
-    for (int cc = 0; cc < NCH; ++cc)
+      for (int cc = 0; cc < NCH; ++cc)
 #pragma unroll
-      for (int q = 0; q < V; ++q) hsk_adamw_replay<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+        for (int q = 0; q < V; ++q) hsk_adamw_replay<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+    }
   }
   hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
   hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
