@@ -53,7 +53,10 @@ static int hsk_part_rule(int64_t n_items, int64_t dim, int64_t batch, int64_t n_
     P = env;
   } else {
     const double mb = (double)n_items * (double)dim * 4.0 / (1024.0 * 1024.0);
-    P = mb <= 4.5 ? 1 : mb <= 12.0 ? 2 : mb <= 24.0 ? 4 : mb <= 64.0 ? 8 : 1;
+    // measured per step at D = 512, N = 100, B = 4096 (rule vs no partitions): 7.6 MB (P = 2) 180 vs 182 us, 21.9 MB
+    // (P = 4) 199 vs 220, 41 MB (P = 8) 250 vs 259, 61 MB (P = 8) 298 vs 295: beyond ~48 MB the partial rows cost more
+    // than the L2 share gains
+    P = mb <= 4.5 ? 1 : mb <= 12.0 ? 2 : mb <= 24.0 ? 4 : mb <= 48.0 ? 8 : 1;
   }
   while (P > 1 && n_neg < 8 * P) P >>= 1;
   return P;
@@ -1060,7 +1063,8 @@ static int64_t hsk_graph_chunk(const hsk_bprmf_state* st) {
   if (st->dim % 2 != 0) return 0;                         // the merged item + user launch carries the descriptor
   if ((st->lazy_users || st->lazy_items) && !hsk_adam_tab_saturates(st)) return 0;
   if (st->step + 2 * HSK_GRAPH_DEFAULT_CHUNK >= HSK_ADAM_TAB_LEN && !hsk_adam_tab_saturates(st)) return 0;
-  return st->graph_chunk > 0 ? st->graph_chunk : HSK_GRAPH_DEFAULT_CHUNK;
+  static const int env_chunk = getenv("HSK_GRAPH_CHUNK") ? atoi(getenv("HSK_GRAPH_CHUNK")) : 0;   // experiments
+  return st->graph_chunk > 0 ? st->graph_chunk : env_chunk > 1 ? env_chunk : HSK_GRAPH_DEFAULT_CHUNK;
 }
 
 // capture `n` steps of `batch` positives starting (relative to the descriptor) at step 0, first buffer set `set0`
