@@ -221,6 +221,43 @@ __device__ void hsk_bitonic_desc(unsigned long long* s, int n) {
   __syncthreads();
 }
 
+// Of 256 bin counts h[0..255] (LDS): the highest bin b with (keys in bins above b) < need <= (those + h[b]), found by
+// wave 0 -- lane l owns bins 4l .. 4l+3, a suffix sum over the lanes -- instead of one thread walking 256 dependent LDS
+// reads (7 us per walk, and a selection makes several).  No such bin (fewer than `need` keys in bins 1..255): bin 0.
+// Every lane of wave 0 returns the same (bin, keys above it, keys in it); other waves must not call.
+struct hsk_bin_pick { unsigned int bin, above, count; };
+__device__ __forceinline__ hsk_bin_pick hsk_pick_bin_256(const unsigned int* h, unsigned int need, int lane) {
+  const unsigned int c0 = h[lane * 4], c1 = h[lane * 4 + 1], c2 = h[lane * 4 + 2], c3 = h[lane * 4 + 3];
+  const unsigned int mine = c0 + c1 + c2 + c3;
+  unsigned int suf = mine;   // inclusive suffix sum over lanes >= this one
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int t = __shfl_down(suf, off, 64);
+    if (lane + off < 64) suf += t;
+  }
+  const unsigned int a3 = suf - mine, a2 = a3 + c3, a1 = a2 + c2, a0 = a1 + c1;
+  int fb = -1;
+  unsigned int fa = 0, fc = 0;
+  if (a3 < need && need <= a3 + c3) { fb = lane * 4 + 3; fa = a3; fc = c3; }
+  else if (a2 < need && need <= a2 + c2) { fb = lane * 4 + 2; fa = a2; fc = c2; }
+  else if (a1 < need && need <= a1 + c1) { fb = lane * 4 + 1; fa = a1; fc = c1; }
+  else if (a0 < need && need <= a0 + c0 && lane * 4 > 0) { fb = lane * 4; fa = a0; fc = c0; }
+  const unsigned long long who = __ballot(fb > 0);
+  hsk_bin_pick r;
+  if (who) {
+    const int src = 63 - __builtin_clzll(who);   // the highest such bin
+    r.bin = (unsigned)__shfl(fb, src, 64);
+    r.above = __shfl(fa, src, 64);
+    r.count = __shfl(fc, src, 64);
+  } else {                                       // bin 0 takes what is left
+    const unsigned int total = __shfl(suf, 0, 64), h0 = __shfl(c0, 0, 64);
+    r.bin = 0;
+    r.above = total - h0;
+    r.count = h0;
+  }
+  return r;
+}
+
 template <typename IdxOut>
 __global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, long long ld, int cols, int k,
                                                    int kpad, long long idx_offset, float* __restrict__ out_vals,
@@ -240,10 +277,31 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, 
   // may be.  If those candidates fit into LDS they are gathered in one more pass and sorted there (key descending,
   // index ascending -- the same tie rule as below).  Rows with more candidates than that (long runs of equal scores,
   // e.g. -inf) take the general 4 x 8-bit radix select below.
+  // Rows of up to 256 x TOPK_RPT columns are read ONCE: every thread keeps its TOPK_RPT keys in registers (all loads in
+  // flight together) and the k-th largest key's prefix is narrowed 8 bits at a time by histograms over the registers:
+  // first the top 8 bits -- where scores of one magnitude all meet in a few bins, so every bin has 16 replicas (by
+  // lane) or the LDS atomics serialise: that contention, not the row's bytes, was what this kernel spent its time on --
+  // then 8 more bits among the keys of that bin, until only a few keys beyond k are left to sort.
+  constexpr int TOPK_RPT = 64;
+  const bool in_regs = cols <= 256 * TOPK_RPT;
+  uint32_t kreg[TOPK_RPT];
   if (cols >= 4096) {
     for (int c = tid; c < 4096; c += 256) hist12[c] = 0;
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < TOPK_RPT; ++i) {
+        const int c = tid + 256 * i;
+        kreg[i] = (c < cols) ? hsk_f2key(row[c]) : 0u;
+      }
+    }
     __syncthreads();
-    for (int c = tid; c < cols; c += 256) atomicAdd(&hist12[hsk_f2key(row[c]) >> 20], 1u);
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < TOPK_RPT; ++i)
+        if (tid + 256 * i < cols) atomicAdd(&hist12[(kreg[i] >> 24) * 16 + (tid & 15)], 1u);
+    } else {
+      for (int c = tid; c < cols; c += 256) atomicAdd(&hist12[hsk_f2key(row[c]) >> 20], 1u);
+    }
     __syncthreads();
     {
       unsigned int sum = 0;
@@ -252,39 +310,90 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, 
       part12[tid] = sum;
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned int cum = 0;   // keys in bins above the current one
-      int g = 255;
-      for (; g > 0; --g) {
-        if (cum + part12[g] >= (unsigned)k) break;
-        cum += part12[g];
+    if (tid < 64) {
+      const hsk_bin_pick pk = hsk_pick_bin_256(part12, (unsigned)k, tid);   // group of 16 bins (or 8-bit bin)
+      if (tid == 0) {
+        unsigned int cum = pk.above;   // keys in bins above the current one
+        const int g = (int)pk.bin;
+        if (in_regs) {                       // 8-bit bins (16 replicas each)
+          sh_prefix = (unsigned)g;
+          sh_ngt = cum;
+          sh_neq = pk.count;
+        } else {
+          int bin = g * 16 + 15;
+          for (; bin > g * 16; --bin) {
+            if (cum + hist12[bin] >= (unsigned)k) break;
+            cum += hist12[bin];
+          }
+          sh_prefix = (unsigned)bin;         // b1
+          sh_ngt = cum;                      // keys in higher bins (< k)
+          sh_neq = hist12[bin];              // keys in b1
+        }
+        sh_taken = 0;
       }
-      int bin = g * 16 + 15;
-      for (; bin > g * 16; --bin) {
-        if (cum + hist12[bin] >= (unsigned)k) break;
-        cum += hist12[bin];
-      }
-      sh_prefix = (unsigned)bin;         // b1
-      sh_ngt = cum;                      // keys in higher bins (< k)
-      sh_neq = hist12[bin];              // keys in b1
-      sh_taken = 0;
     }
     __syncthreads();
-    const unsigned int b1 = sh_prefix, n_cand = sh_ngt + sh_neq;
+    unsigned int b1 = sh_prefix, n_cand = sh_ngt + sh_neq;
+    int cshift = in_regs ? 24 : 20;   // candidates: keys with (key >> cshift) >= b1
+    while (in_regs && cshift >= 8 && n_cand > 2u * (unsigned)kpad) {
+      // 8 more bits among the keys that share the current prefix
+      __syncthreads();
+      hist[tid] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TOPK_RPT; ++i)
+        if (tid + 256 * i < cols && (kreg[i] >> cshift) == b1) atomicAdd(&hist[(kreg[i] >> (cshift - 8)) & 0xffu], 1u);
+      __syncthreads();
+      if (tid < 64) {
+        const hsk_bin_pick pk = hsk_pick_bin_256(hist, (unsigned)k - sh_ngt, tid);   // need >= 1: the k-th largest carries the prefix
+        if (tid == 0) {
+          sh_prefix = (b1 << 8) | pk.bin;
+          sh_ngt += pk.above;
+          sh_neq = pk.count;
+        }
+      }
+      __syncthreads();
+      b1 = sh_prefix;
+      n_cand = sh_ngt + sh_neq;
+      cshift -= 8;
+    }
     if (n_cand <= TOPK_CAND_MAX) {
       int npad = 1;
       while (npad < (int)n_cand) npad <<= 1;
       if (npad < kpad) npad = kpad;
       for (int c = tid; c < npad; c += 256) cand[c] = 0ull;   // pads sort last
       __syncthreads();
-      for (int c = tid; c < cols; c += 256) {
-        const uint32_t key = hsk_f2key(row[c]);
-        if ((key >> 20) >= b1) {
-          const unsigned int slot = atomicAdd(&sh_taken, 1u);
-          cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)c);
+      if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < TOPK_RPT; ++i) {
+          const int c = tid + 256 * i;
+          if (c < cols && (kreg[i] >> cshift) >= b1) {
+            const unsigned int slot = atomicAdd(&sh_taken, 1u);
+            cand[slot] = ((unsigned long long)kreg[i] << 32) | (uint32_t)(~(uint32_t)c);
+          }
+        }
+      } else {
+        for (int c = tid; c < cols; c += 256) {
+          const uint32_t key = hsk_f2key(row[c]);
+          if ((key >> 20) >= b1) {
+            const unsigned int slot = atomicAdd(&sh_taken, 1u);
+            cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)c);
+          }
         }
       }
       __syncthreads();
+      if (n_cand <= 256) {
+        // a few keys beyond k: every thread ranks its own candidate by counting the larger ones (composite keys are
+        // unique; broadcast LDS reads) -- one pass instead of the 36 barrier-separated stages of a bitonic sort
+        const unsigned long long mine = (tid < (int)n_cand) ? cand[tid] : 0ull;
+        int rank = 0;
+        for (int j = 0; j < (int)n_cand; ++j) rank += (cand[j] > mine) ? 1 : 0;
+        if (tid < (int)n_cand && rank < k) {
+          out_vals[(long long)blockIdx.x * k + rank] = hsk_key2f((uint32_t)(mine >> 32));
+          out_idx[(long long)blockIdx.x * k + rank] = (IdxOut)((long long)(~(uint32_t)mine) + idx_offset);
+        }
+        return;
+      }
       hsk_bitonic_desc(cand, npad);
       for (int c = tid; c < k; c += 256) {
         const unsigned long long v = cand[c];
@@ -307,16 +416,13 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, 
       if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned int cum = 0;
-      int bin = 255;
-      for (; bin > 0; --bin) {
-        if (cum + hist[bin] >= need) break;
-        cum += hist[bin];
+    if (tid < 64) {
+      const hsk_bin_pick pk = hsk_pick_bin_256(hist, need, tid);
+      if (tid == 0) {
+        sh_prefix = prefix | ((uint32_t)pk.bin << shift);
+        sh_need = need - pk.above;
+        sh_neq = pk.count;
       }
-      sh_prefix = prefix | ((uint32_t)bin << shift);
-      sh_need = need - cum;
-      sh_neq = hist[bin];
     }
     __syncthreads();
     prefix = sh_prefix;
