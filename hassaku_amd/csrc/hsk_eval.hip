@@ -23,7 +23,7 @@ typedef float hsk_f32x16 __attribute__((ext_vector_type(16)));
 #define GEMM_LDS_STRIDE (GEMM_BK + 4)
 
 template <bool VEC4>
-__global__ __launch_bounds__(256) void k_score_gemm(const float* __restrict__ Uw, const float* __restrict__ Iw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_score_gemm(const float* __restrict__ Uw, const float* __restrict__ Iw,
                                                     const float* __restrict__ Ib, const float* __restrict__ Ub,
                                                     const float* __restrict__ gb, int n_users, int D,
                                                     const int64_t* __restrict__ u_idx, int n_rows, long long item_begin,
