@@ -259,7 +259,7 @@ __device__ __forceinline__ hsk_bin_pick hsk_pick_bin_256(const unsigned int* h, 
 }
 
 template <typename IdxOut>
-__global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, long long ld, int cols, int k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_topk_rows(const float* __restrict__ X, long long ld, int cols, int k,
                                                    int kpad, long long idx_offset, float* __restrict__ out_vals,
                                                    IdxOut* __restrict__ out_idx) {
   __shared__ unsigned int hist[256];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_topk_rows(const float* __restrict__ X, 
   // first the top 8 bits -- where scores of one magnitude all meet in a few bins, so every bin has 16 replicas (by
   // lane) or the LDS atomics serialise: that contention, not the row's bytes, was what this kernel spent its time on --
   // then 8 more bits among the keys of that bin, until only a few keys beyond k are left to sort.
-  constexpr int TOPK_RPT = 64;
+  constexpr int TOPK_RPT = 48;
   const bool in_regs = cols <= 256 * TOPK_RPT;
   uint32_t kreg[TOPK_RPT];
   if (cols >= 4096) {
