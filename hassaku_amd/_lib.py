@@ -90,6 +90,7 @@ SIGNATURES = {
     'hsk_bprmf_last_sort': (c_int, [POINTER(HskBprmfState), c_int64, c_void_p, c_void_p, c_void_p]),
     'hsk_bprmf_graph_replays': (c_int64, [POINTER(HskBprmfState)]),
     'hsk_bprmf_batch_columns': (c_int64, [POINTER(HskBprmfState), c_int64, c_int64]),
+    'hsk_eval_set_arith': (None, [c_int]),
     'hsk_timing_create': (c_void_p, []),
     'hsk_timing_destroy': (None, [c_void_p]),
     'hsk_timing_collect': (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),

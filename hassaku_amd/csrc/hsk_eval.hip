@@ -4,6 +4,7 @@
 // Reference semantics restated: eval/eval.py:237-253 (scores, -inf mask), eval/eval.py:54-99
 // (topk(100), k in {100,50,10,5}), eval/metrics.py:4-105 (precision / recall / ndcg).
 #include "hsk_common.h"
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -136,6 +137,202 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
+    }
+    __syncthreads();
+    if (has_next) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const float gbv = gb ? gb[0] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l32;
+      if (col >= item_count) continue;
+      const float ib = Ib ? Ib[item_begin + col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rloc = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        const int row = m0 + rloc;
+        if (row < n_rows) {
+          float o = acc[i][j][q];
+          if (Ub) o += Ub[urow[rloc]];  // reference order: += u_bias, += i_bias, += global_bias
+          if (Ib) o += ib;
+          if (gb) o += gbv;
+          C[(long long)row * item_count + col] = o;
+        }
+      }
+    }
+}
+
+// Which arithmetic the materialised score GEMM uses: 1 (default) the three-piece bf16 form (k_score_gemm_x3), 0 the
+// exact-fp32 MFMA form (k_score_gemm; also what the fused kernel of hsk_eval_fused.hip computes).  HSK_EVAL_X3 in the
+// environment sets the initial value, hsk_eval_set_arith changes it (parity tests compare the two forms).
+static int g_eval_x3 = -1;
+static int hsk_eval_x3() {
+  if (g_eval_x3 < 0) g_eval_x3 = getenv("HSK_EVAL_X3") ? (atoi(getenv("HSK_EVAL_X3")) != 0) : 1;
+  return g_eval_x3;
+}
+extern "C" void hsk_eval_set_arith(int three_piece_bf16) { g_eval_x3 = three_piece_bf16 ? 1 : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// The same scores from bf16 matrix cores.  Every fp32 operand is cut into three bf16 pieces while its tile is staged into
+// LDS (x = x1 + x2 + x3: 8 + 8 + 8 significant bits, each cut exact in fp32); of the nine products per (a, b) pair the six
+// of weight >= 2^-16 are kept, each a v_mfma_f32_32x32x16_bf16 into the same fp32 accumulator.  A bf16 x bf16 product is
+// exact in fp32 and the dropped terms are <= 2^-24 |a||b|: fp32-GEMM accuracy (measured: 5e-7 of the largest score
+// against float64, profiles/probes/gemm_bf16x3.hip) -- at six 32-cycle MFMAs where the fp32 form needs sixteen 64-cycle
+// ones per 32 x 32 x 32 block.  Non-finite operands keep their value in the first piece (the other two are zero).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 hsk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hsk_bf16x4 __attribute__((ext_vector_type(4)));
+#define GEMM_X3_LDK (GEMM_BK + 8)   // LDS row stride in bf16 elements: 80 B, ds_read_b128 conflict-free
+
+__device__ __forceinline__ void hsk_split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float hf = (float)h;
+  const bool fin = __builtin_isfinite(hf);   // inf / nan (also a finite x that rounds to bf16 inf): one piece
+  const float r1 = fin ? x - hf : 0.f;
+  m = (__bf16)r1;
+  const float r2 = r1 - (float)m;
+  l = (__bf16)r2;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256, 2) void k_score_gemm_x3(const float* __restrict__ Uw, const float* __restrict__ Iw,
+                                                    const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                    const float* __restrict__ gb, int n_users, int D,
+                                                    const int64_t* __restrict__ u_idx, int n_rows, long long item_begin,
+                                                    int item_count, float* __restrict__ C, int32_t* status) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[3][GEMM_BM * GEMM_X3_LDK];   // the three bf16 pieces of the tile
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][GEMM_BN * GEMM_X3_LDK];
+  __shared__ int urow[GEMM_BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GEMM_BM;
+  const int n0 = blockIdx.x * GEMM_BN;
+
+  if (tid < GEMM_BM) {
+    int r = m0 + tid;
+    int u = 0;
+    if (r < n_rows) {
+      long long uu = u_idx[r];
+      if (uu < 0 || uu >= n_users) {
+        if (status) atomicOr(status, HSK_STATUS_BAD_INDEX);
+        uu = 0;
+      }
+      u = (int)uu;
+    }
+    urow[tid] = u;
+  }
+  __syncthreads();
+
+  hsk_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // staging assignment: 8 threads cover the 32 floats (128 B) of one row; 32 rows per pass, 4 passes
+  const int srow = tid >> 3;
+  const int scol = (tid & 7) * 4;
+  const int half = lane >> 5;
+  const int l32 = lane & 31;
+
+  // Register-staged double buffering: the global loads of k-tile t+1 are issued before the MFMAs of tile t and
+  // land in registers while the matrix cores work; they go to LDS after the tile's last read.  (Loading straight
+  // into LDS inside the loop left the memory latency of every tile exposed: 78 TFLOP/s; staged: see DESIGN.md.)
+  float4 ra[4], rb[4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = srow + pass * 32;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < n_rows) {   // A: user rows (gathered through urow)
+        const float* src = Uw + (long long)urow[r] * D + k0 + scol;
+        if (VEC4) {
+          if (k0 + scol < D) va = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k0 + scol + 0 < D) va.x = src[0];
+          if (k0 + scol + 1 < D) va.y = src[1];
+          if (k0 + scol + 2 < D) va.z = src[2];
+          if (k0 + scol + 3 < D) va.w = src[3];
+        }
+      }
+      if (n0 + r < item_count) {   // B: item rows of the shard
+        const float* src = Iw + (item_begin + n0 + r) * (long long)D + k0 + scol;
+        if (VEC4) {
+          if (k0 + scol < D) vb = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k0 + scol + 0 < D) vb.x = src[0];
+          if (k0 + scol + 1 < D) vb.y = src[1];
+          if (k0 + scol + 2 < D) vb.z = src[2];
+          if (k0 + scol + 3 < D) vb.w = src[3];
+        }
+      }
+      ra[pass] = va;
+      rb[pass] = vb;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = srow + pass * 32;
+      hsk_bf16x4 a1, a2, a3, b1, b2, b3;
+      const float av[4] = {ra[pass].x, ra[pass].y, ra[pass].z, ra[pass].w};
+      const float bv[4] = {rb[pass].x, rb[pass].y, rb[pass].z, rb[pass].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 x1, x2, x3;
+        hsk_split3(av[e], x1, x2, x3);
+        a1[e] = x1; a2[e] = x2; a3[e] = x3;
+        hsk_split3(bv[e], x1, x2, x3);
+        b1[e] = x1; b2[e] = x2; b3[e] = x3;
+      }
+      *reinterpret_cast<hsk_bf16x4*>(&As[0][r * GEMM_X3_LDK + scol]) = a1;
+      *reinterpret_cast<hsk_bf16x4*>(&As[1][r * GEMM_X3_LDK + scol]) = a2;
+      *reinterpret_cast<hsk_bf16x4*>(&As[2][r * GEMM_X3_LDK + scol]) = a3;
+      *reinterpret_cast<hsk_bf16x4*>(&Bs[0][r * GEMM_X3_LDK + scol]) = b1;
+      *reinterpret_cast<hsk_bf16x4*>(&Bs[1][r * GEMM_X3_LDK + scol]) = b2;
+      *reinterpret_cast<hsk_bf16x4*>(&Bs[2][r * GEMM_X3_LDK + scol]) = b3;
+    }
+  };
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int k0 = 0; k0 < D; k0 += GEMM_BK) {
+    const bool has_next = k0 + GEMM_BK < D;
+    if (has_next) load_tile(k0 + GEMM_BK);
+
+#pragma unroll
+    for (int s16 = 0; s16 < 2; ++s16) {   // two k = 16 steps per tile; lane (r = l32, h = half) holds k = 8h .. 8h+7 of a step
+      hsk_bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          a[pl][i] = *reinterpret_cast<const hsk_bf16x8*>(&As[pl][(wm * 64 + i * 32 + l32) * GEMM_X3_LDK + 16 * s16 + 8 * half]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[pl][j] = *reinterpret_cast<const hsk_bf16x8*>(&Bs[pl][(wn * 64 + j * 32 + l32) * GEMM_X3_LDK + 16 * s16 + 8 * half]);
+      }
+      // the six products of weight >= 2^-16, smallest first: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
+      constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
     if (has_next) {
@@ -611,14 +808,16 @@ extern "C" int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, co
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid((unsigned)hsk_ceil_div(item_count, GEMM_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_BM));
   const bool vec4 = (dim % 4 == 0) && ((((uintptr_t)user_emb | (uintptr_t)item_emb) & 15) == 0);
-  if (vec4)
-    k_score_gemm<true><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
-                                                 (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
-                                                 scores_ws, status);
-  else
-    k_score_gemm<false><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
-                                                  (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
-                                                  scores_ws, status);
+  const int x3 = hsk_eval_x3();
+#define HSK_SCORE_GEMM(KERNEL)                                                                                        \
+  KERNEL<<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users, (int)dim, u_idx, \
+                                   (int)n_rows, (long long)item_begin, (int)item_count, scores_ws, status)
+  if (x3) {
+    if (vec4) HSK_SCORE_GEMM(k_score_gemm_x3<true>); else HSK_SCORE_GEMM(k_score_gemm_x3<false>);
+  } else {
+    if (vec4) HSK_SCORE_GEMM(k_score_gemm<true>); else HSK_SCORE_GEMM(k_score_gemm<false>);
+  }
+#undef HSK_SCORE_GEMM
   HSK_LAUNCH_CHECK();
   if (excl_indptr) {
     k_mask_excluded<<<(unsigned)hsk_ceil_div(n_rows, 4), 256, 0, stream>>>(

@@ -556,6 +556,12 @@ FUSED_TOPK_MIN_ITEMS = 32768   # below this many columns the warm-up of the in-G
 _fused_ws = {}             # device -> scratch of the fused selection, grown on demand
 
 
+def set_eval_arith(three_piece_bf16: bool):
+    """Arithmetic of the materialised score GEMM: True (default) three bf16 pieces per fp32 operand, False exact fp32
+    MFMA (what the fused top-k kernel computes); see hsk_eval_set_arith in include/hassaku_hip.h."""
+    _lib.load().hsk_eval_set_arith(1 if three_piece_bf16 else 0)
+
+
 def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k, excl_indptr=None, excl_indices=None,
                  item_begin=0, item_count=None, scores_ws=None, status=None, item_shard=False, n_items_global=None,
                  want_scores=None):
