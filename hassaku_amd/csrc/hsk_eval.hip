@@ -169,11 +169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-// Which arithmetic the materialised score GEMM uses: 1 (default) the three-piece bf16 form (k_score_gemm_x3), 0 the
-// exact-fp32 MFMA form (k_score_gemm; also what the fused kernel of hsk_eval_fused.hip computes).  HSK_EVAL_X3 in the
-// environment sets the initial value, hsk_eval_set_arith changes it (parity tests compare the two forms).
+// Which arithmetic the score GEMMs use (k_score_gemm* here, k_score_topk<.., X3> in hsk_eval_fused.hip): 1 (default) the
+// three-piece bf16 form, 0 the exact-fp32 MFMA form.  HSK_EVAL_X3 in the environment sets the initial value,
+// hsk_eval_set_arith changes it (parity tests compare the two forms).
 static int g_eval_x3 = -1;
-static int hsk_eval_x3() {
+int hsk_eval_x3() {   // also called from hsk_eval_fused.hip
   if (g_eval_x3 < 0) g_eval_x3 = getenv("HSK_EVAL_X3") ? (atoi(getenv("HSK_EVAL_X3")) != 0) : 1;
   return g_eval_x3;
 }

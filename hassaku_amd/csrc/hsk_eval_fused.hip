@@ -22,6 +22,19 @@
 typedef float hsk_f32x16 __attribute__((ext_vector_type(16)));
 
 #define FG_BM 128
+#define FG_X3_LDK 40   // = GEMM_X3_LDK of hsk_eval.hip: LDS row stride of a bf16 plane, in elements
+typedef __bf16 fg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 fg_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fg_split3(float x, __bf16& h, __bf16& m, __bf16& l) {   // = hsk_split3 of hsk_eval.hip
+  h = (__bf16)x;
+  const float hf = (float)h;
+  const bool fin = __builtin_isfinite(hf);
+  const float r1 = fin ? x - hf : 0.f;
+  m = (__bf16)r1;
+  const float r2 = r1 - (float)m;
+  l = (__bf16)r2;
+}
+int hsk_eval_x3();   // hsk_eval.hip: which arithmetic the score GEMMs use
 #define FG_BN 128
 #define FG_BK 32
 #define FG_LDS_STRIDE (FG_BK + 4)
@@ -62,7 +75,9 @@ __device__ __forceinline__ void fg_wave_bitonic_desc(unsigned long long* s, int 
   __builtin_amdgcn_wave_barrier();
 }
 
-template <bool VEC4>
+// X3: the GEMM core of k_score_gemm_x3 (hsk_eval.hip): three bf16 pieces per fp32 operand, six bf16 MFMAs per block, the
+// same order of operations -- so the two paths stay bit-equal in either arithmetic
+template <bool VEC4, bool X3>
 __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__ Uw, const float* __restrict__ Iw,
                                                     const float* __restrict__ Ib, const float* __restrict__ Ub,
                                                     const float* __restrict__ gb, int n_users, int D,
@@ -73,8 +88,14 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
                                                     unsigned long long* __restrict__ cand_ws,
                                                     float* __restrict__ part_vals, int32_t* __restrict__ part_idx,
                                                     int32_t* status) {
-  __shared__ __attribute__((aligned(16))) float As[FG_BM * FG_LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Bs[FG_BN * FG_LDS_STRIDE];
+  // fp32 tiles [row][32+4], or (X3) three bf16 planes [row][32+8] each
+  constexpr int TILE_BYTES = X3 ? 3 * FG_BM * FG_X3_LDK * 2 : FG_BM * FG_LDS_STRIDE * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char As_raw[TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs_raw[TILE_BYTES];
+  float* As = reinterpret_cast<float*>(As_raw);
+  float* Bs = reinterpret_cast<float*>(Bs_raw);
+  __bf16* Ap = reinterpret_cast<__bf16*>(As_raw);   // plane pl at Ap + pl * FG_BM * FG_X3_LDK
+  __bf16* Bp = reinterpret_cast<__bf16*>(Bs_raw);
   __shared__ unsigned long long srt[4][HSK_SEL_KMAX];   // per-wave scratch of the final sort (k <= 128 keys)
   __shared__ unsigned int hist[4][256];                 // per-wave digit histogram of the selection
   __shared__ int urow[FG_BM];
@@ -293,8 +314,29 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int r = srow + pass * 32;
-        *reinterpret_cast<float4*>(&As[r * FG_LDS_STRIDE + scol]) = ra[pass];
-        *reinterpret_cast<float4*>(&Bs[r * FG_LDS_STRIDE + scol]) = rbv[pass];
+        if (X3) {
+          fg_bf16x4 a1, a2, a3, b1, b2, b3;
+          const float av[4] = {ra[pass].x, ra[pass].y, ra[pass].z, ra[pass].w};
+          const float bv[4] = {rbv[pass].x, rbv[pass].y, rbv[pass].z, rbv[pass].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            __bf16 x1, x2, x3;
+            fg_split3(av[e], x1, x2, x3);
+            a1[e] = x1; a2[e] = x2; a3[e] = x3;
+            fg_split3(bv[e], x1, x2, x3);
+            b1[e] = x1; b2[e] = x2; b3[e] = x3;
+          }
+          constexpr int PL = FG_BM * FG_X3_LDK;
+          *reinterpret_cast<fg_bf16x4*>(&Ap[0 * PL + r * FG_X3_LDK + scol]) = a1;
+          *reinterpret_cast<fg_bf16x4*>(&Ap[1 * PL + r * FG_X3_LDK + scol]) = a2;
+          *reinterpret_cast<fg_bf16x4*>(&Ap[2 * PL + r * FG_X3_LDK + scol]) = a3;
+          *reinterpret_cast<fg_bf16x4*>(&Bp[0 * PL + r * FG_X3_LDK + scol]) = b1;
+          *reinterpret_cast<fg_bf16x4*>(&Bp[1 * PL + r * FG_X3_LDK + scol]) = b2;
+          *reinterpret_cast<fg_bf16x4*>(&Bp[2 * PL + r * FG_X3_LDK + scol]) = b3;
+        } else {
+          *reinterpret_cast<float4*>(&As[r * FG_LDS_STRIDE + scol]) = ra[pass];
+          *reinterpret_cast<float4*>(&Bs[r * FG_LDS_STRIDE + scol]) = rbv[pass];
+        }
       }
     };
     if (tile == t_lo) load_tile(n0, 0);   // later tiles: loaded under the previous tile's epilogue
@@ -303,6 +345,30 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
     for (int k0 = 0; k0 < D; k0 += FG_BK) {
       const bool has_next = k0 + FG_BK < D;
       if (has_next) load_tile(n0, k0 + FG_BK);
+      if (X3) {
+        constexpr int PL = FG_BM * FG_X3_LDK;
+#pragma unroll
+        for (int s16 = 0; s16 < 2; ++s16) {   // two k = 16 steps per tile (see k_score_gemm_x3)
+          fg_bf16x8 a[3][2], b[3][2];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              a[pl][i] = *reinterpret_cast<const fg_bf16x8*>(&Ap[pl * PL + (wm * 64 + i * 32 + l32) * FG_X3_LDK + 16 * s16 + 8 * half]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              b[pl][j] = *reinterpret_cast<const fg_bf16x8*>(&Bp[pl * PL + (wn * 64 + j * 32 + l32) * FG_X3_LDK + 16 * s16 + 8 * half]);
+          }
+          constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 a[2], b[2];
@@ -321,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
           }
+      }
       }
       __syncthreads();
       if (has_next) {
@@ -483,16 +550,17 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
   const bool vec4 = (dim % 4 == 0) && ((((uintptr_t)user_emb | (uintptr_t)item_emb) & 15) == 0);
   float* pv = S == 1 ? out_vals : part_vals;
   int32_t* pi = S == 1 ? out_idx : part_idx;
-  if (vec4)
-    k_score_topk<true><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
-                                                 (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
-                                                 tiles_per_split, excl_indptr, excl_indices, (int)k, S, slab, pv, pi,
-                                                 status);
-  else
-    k_score_topk<false><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,
-                                                  (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,
-                                                  tiles_per_split, excl_indptr, excl_indices, (int)k, S, slab, pv, pi,
-                                                  status);
+#define HSK_SCORE_TOPK(V4, X3)                                                                                          \
+  k_score_topk<V4, X3><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,    \
+                                                 (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,   \
+                                                 tiles_per_split, excl_indptr, excl_indices, (int)k, S, slab, pv, pi,     \
+                                                 status)
+  if (hsk_eval_x3()) {
+    if (vec4) HSK_SCORE_TOPK(true, true); else HSK_SCORE_TOPK(false, true);
+  } else {
+    if (vec4) HSK_SCORE_TOPK(true, false); else HSK_SCORE_TOPK(false, false);
+  }
+#undef HSK_SCORE_TOPK
   HSK_LAUNCH_CHECK();
   if (S > 1) {
     int npad = 1;

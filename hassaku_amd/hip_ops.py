@@ -557,8 +557,8 @@ _fused_ws = {}             # device -> scratch of the fused selection, grown on 
 
 
 def set_eval_arith(three_piece_bf16: bool):
-    """Arithmetic of the materialised score GEMM: True (default) three bf16 pieces per fp32 operand, False exact fp32
-    MFMA (what the fused top-k kernel computes); see hsk_eval_set_arith in include/hassaku_hip.h."""
+    """Arithmetic of the score GEMMs (materialised and fused top-k): True (default) three bf16 pieces per fp32 operand,
+    False exact fp32 MFMA; see hsk_eval_set_arith in include/hassaku_hip.h."""
     _lib.load().hsk_eval_set_arith(1 if three_piece_bf16 else 0)
 
 

@@ -310,9 +310,10 @@ int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
 int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols,
                          int64_t* u_out, int64_t* i_out, hsk_stream_t stream);
 
-/* Arithmetic of the materialised score GEMM (hsk_mf_eval_topk with a score buffer): 1 (default) = every fp32 operand cut
- * into three bf16 pieces, six bf16 MFMAs per product block -- fp32-GEMM accuracy (<= 1e-6 of the largest score against
- * float64) at about twice the rate; 0 = the exact-fp32 MFMA form, which is also what hsk_mf_eval_topk_fused computes.
+/* Arithmetic of the score GEMMs of hsk_mf_eval_topk and hsk_mf_eval_topk_fused: 1 (default) = every fp32 operand cut into
+ * three bf16 pieces, six bf16 MFMAs per product block -- fp32-GEMM accuracy (<= 1e-6 of the largest score against
+ * float64) at 1.2-1.5x the rate; 0 = the exact-fp32 MFMA form.  Both entry points follow the switch and the same order of
+ * operations, so the materialised and the fused path agree bit for bit in either form.
  * Process-wide; the environment variable HSK_EVAL_X3 sets the initial value.  (Replaces nothing in the reference: its
  * scores are torch's fp32 matmul, eval/eval.py:240-248; both forms meet the 1e-5 bound against it.) */
 void hsk_eval_set_arith(int three_piece_bf16);

@@ -660,17 +660,25 @@ def test_fused_topk_equals_materialised_topk(ops, shape):
     same values, same ids, same order -- with biases, exclusions (one user with fewer than k admissible items: the
     -inf entries fill up, lowest id first), exact ties (duplicated item rows) and an item range."""
     R, n_users, n_items, D, k = shape
-    ops.set_eval_arith(False)     # the materialised GEMM in the fused kernel's arithmetic (exact-fp32 MFMA): bit-equal
+    # both kernels follow the same arithmetic switch and the same order of operations: bit-equal in either form
     try:
-        _fused_vs_materialised(ops, R, n_users, n_items, D, k, exact=True)
+        for x3 in (False, True):
+            ops.set_eval_arith(x3)
+            _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross=False)
     finally:
         ops.set_eval_arith(True)
-    # and against the default materialised form (three bf16 pieces per operand): values to 4e-6 of the largest score,
-    # ids wherever neighbouring scores are clearly further apart than that
-    _fused_vs_materialised(ops, R, n_users, n_items, D, k, exact=False)
+    # the two forms against each other (materialised exact-fp32 vs fused three-piece bf16): values to 4e-6 of the largest
+    # score, ids wherever neighbouring scores are clearly further apart than that
+    _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross=True)
 
 
-def _fused_vs_materialised(ops, R, n_users, n_items, D, k, exact):
+def _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross):
+    exact = not cross
+
+    def arith(materialised):   # cross: the materialised reference in exact fp32, the fused path in the default form
+        if cross:
+            ops.set_eval_arith(not materialised)
+
     g = torch.Generator(device='cuda').manual_seed(7)
     U = torch.randn(n_users, D, device='cuda', generator=g) * 0.3
     I = torch.randn(n_items, D, device='cuda', generator=g) * 0.3
@@ -690,14 +698,18 @@ def _fused_vs_materialised(ops, R, n_users, n_items, D, k, exact):
     u[0] = 1
     for lo, cnt in ((0, n_items), (n_items // 3, n_items - n_items // 3 - 7)):
         kk = min(k, cnt)
+        arith(True)
         v_ref, i_ref, sc = ops.mf_eval_topk(U, I, Ib, Ub, gb, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo,
                                             item_count=cnt, want_scores=True)
+        arith(False)
         v, i, none = ops.mf_eval_topk(U, I, Ib, Ub, gb, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
                                       want_scores=False)
         assert none is None and sc is not None
         _same_topk(v, i, v_ref, i_ref, exact, (lo, cnt))
     # without an exclusion CSR and without biases
+    arith(True)
     v_ref, i_ref, _ = ops.mf_eval_topk(U, I, None, None, None, u, min(k, n_items), want_scores=True)
+    arith(False)
     v, i, _ = ops.mf_eval_topk(U, I, None, None, None, u, min(k, n_items), want_scores=False)
     _same_topk(v, i, v_ref, i_ref, exact, 'plain')
 
