@@ -16,6 +16,7 @@
 // lists of a row.  Excluded (user, item) pairs become -inf exactly as in the reference (they can still appear in the
 // top k of a user with fewer than k admissible items, lowest item id first).
 #include "hsk_common.h"
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -497,10 +498,13 @@ __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ v
   }
 }
 
-// number of item splits: enough workgroups to fill the chip (~4 per CU), lists short enough for the merge
+// number of item splits: enough workgroups to fill the chip (2 per CU), lists short enough for the merge
 static int hsk_fused_splits(int64_t n_rows, int64_t item_count, int64_t k) {
   const int64_t row_blocks = hsk_ceil_div(n_rows, FG_BM), n_tiles = hsk_ceil_div(item_count, FG_BN);
-  int64_t s = hsk_ceil_div(1024, row_blocks);
+  // two workgroups of this kernel fit a CU (256 VGPRs): 512 of them are one full round; 1024 (two rounds, twice as many
+  // lists to warm up) measured 748 vs 804 k users/s at the lfm2b shape, 256: 573 k
+  static const int target_wgs = getenv("HSK_FUSED_WGS") ? atoi(getenv("HSK_FUSED_WGS")) : 512;
+  int64_t s = hsk_ceil_div(target_wgs, row_blocks);
   s = std::min<int64_t>(s, 4096 / std::max<int64_t>(k, 1));   // the merge sorts <= 4096 keys per row
   s = std::min<int64_t>(s, std::max<int64_t>(1, n_tiles / 8));   // a split of fewer than 8 tiles is all warm-up
   s = std::max<int64_t>(s, 1);
