@@ -55,6 +55,7 @@ ICACHE_GATHER_GBS = 8600.0   # same guide, "Indexed rows": uniformly random rows
 L2_GATHER_GBS = 17800.0      # same table: rows shared by every workgroup of an XCD (its L2), 16.8-18.8 TB/s chip-wide
 HBM_GATHER_GBS = 5750.0      # same guide: random 2.3 KB rows of a table far beyond the Infinity Cache, 5.7-5.8 TB/s
 MFMA_FP32_TFLOPS = 157.0     # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32; no xf32 on gfx950)
+MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PROFILE_DIR = {'ml10m': 'r2b_ml10m', 'hbm': 'r2_hbm', 'ml1m': 'r2b_ml1m', 'ml100k': 'r2b_ml100k'}  # committed rocprofv3 summaries
 LR, WD = 3e-4, 4e-5          # README.md:82-83 of the reference (canonical BPR-MF conf)
 
@@ -355,7 +356,13 @@ def run_eval(shape, device, comm=None, chunk=None, repeat=3):
                         f'{npos} excluded positives per user, chunks of {chunk} users',
             'n_gpus': world, 'sharding': 'items (range-sharded tables, candidate all_to_all)' if comm is not None else 'none',
             'users_per_s': U / dt, 'seconds_per_full_eval': dt, 'tflops_fp32': tf,
-            'frac_of_fp32_mfma_peak_157': tf / (MFMA_FP32_TFLOPS * world), 'ndcg@10_check': check['ndcg@10']}
+            'frac_of_fp32_mfma_peak_157': tf / (MFMA_FP32_TFLOPS * world),
+            # the score GEMMs run on the bf16 matrix cores: every fp32 operand in three bf16 pieces, six bf16 MFMAs per
+            # product block (fp32-GEMM accuracy; csrc/hsk_eval.hip k_score_gemm_x3) -- 2500 / 6 TFLOP/s fp32-equivalent
+            'arithmetic': 'fp32-accurate scores from three bf16 pieces per operand, six bf16 MFMAs per block (HSK_EVAL_X3=0: exact-fp32 MFMA)'
+                          if os.environ.get('HSK_EVAL_X3', '1') != '0' else 'exact-fp32 MFMA',
+            'frac_of_bf16_six_product_peak_417': tf / (MFMA_BF16_TFLOPS / 6.0 * world),
+            'ndcg@10_check': check['ndcg@10']}
 
 
 # ------------------------------------------------------------------------------------------------
