@@ -455,9 +455,12 @@ __device__ __forceinline__ hsk_bin_pick hsk_pick_bin_256(const unsigned int* h, 
   return r;
 }
 
-template <typename IdxOut>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_topk_rows(const float* __restrict__ X, long long ld, int cols, int k,
-                                                   int kpad, long long idx_offset, float* __restrict__ out_vals,
+// TOPK_RPT keys per thread stay in registers for rows of up to 256 x TOPK_RPT columns: 48 (rows of <= 12 288 columns; the
+// kernel then fits 4 waves per SIMD) or 64 (<= 16 384 columns -- the width of one rank's shard of the 131 072-item
+// catalogue on 8 GPUs -- at 3 waves per SIMD)
+template <typename IdxOut, int TOPK_RPT>
+__device__ __forceinline__ void hsk_topk_rows_body(const float* __restrict__ X, long long ld, int cols, int k, int kpad,
+                                                   long long idx_offset, float* __restrict__ out_vals,
                                                    IdxOut* __restrict__ out_idx) {
   __shared__ unsigned int hist[256];
   __shared__ unsigned long long cand[TOPK_CAND_MAX];
@@ -479,7 +482,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // first the top 8 bits -- where scores of one magnitude all meet in a few bins, so every bin has 16 replicas (by
   // lane) or the LDS atomics serialise: that contention, not the row's bytes, was what this kernel spent its time on --
   // then 8 more bits among the keys of that bin, until only a few keys beyond k are left to sort.
-  constexpr int TOPK_RPT = 48;
   const bool in_regs = cols <= 256 * TOPK_RPT;
   uint32_t kreg[TOPK_RPT];
   if (cols >= 4096) {
@@ -683,6 +685,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+template <typename IdxOut>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_topk_rows(const float* __restrict__ X, long long ld, int cols, int k, int kpad, long long idx_offset,
+                 float* __restrict__ out_vals, IdxOut* __restrict__ out_idx) {
+  hsk_topk_rows_body<IdxOut, 48>(X, ld, cols, k, kpad, idx_offset, out_vals, out_idx);
+}
+template <typename IdxOut>
+__global__ __launch_bounds__(256) void k_topk_rows_wide(const float* __restrict__ X, long long ld, int cols, int k, int kpad,
+                                                        long long idx_offset, float* __restrict__ out_vals,
+                                                        IdxOut* __restrict__ out_idx) {
+  hsk_topk_rows_body<IdxOut, 64>(X, ld, cols, k, kpad, idx_offset, out_vals, out_idx);
+}
+
 static int hsk_next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -782,7 +797,10 @@ __global__ __launch_bounds__(256) void k_rank_metrics(const int32_t* __restrict_
 static int hsk_launch_topk_i32(const float* X, int64_t rows, int64_t cols, int64_t ld, int64_t k, long long off,
                                float* out_vals, int32_t* out_idx, hipStream_t stream) {
   const int kpad = hsk_next_pow2((int)k);
-  k_topk_rows<int32_t><<<(unsigned)rows, 256, 0, stream>>>(X, ld, (int)cols, (int)k, kpad, off, out_vals, out_idx);
+  if (cols > 256 * 48 && cols <= 256 * 64)
+    k_topk_rows_wide<int32_t><<<(unsigned)rows, 256, 0, stream>>>(X, ld, (int)cols, (int)k, kpad, off, out_vals, out_idx);
+  else
+    k_topk_rows<int32_t><<<(unsigned)rows, 256, 0, stream>>>(X, ld, (int)cols, (int)k, kpad, off, out_vals, out_idx);
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
@@ -838,8 +856,12 @@ extern "C" int hsk_topk_dense(const float* logits, int64_t rows, int64_t cols, i
   HSK_REQUIRE(k <= cols, HSK_ERR_INVALID, "k %lld > cols %lld", (long long)k, (long long)cols);
   if (rows == 0) return HSK_OK;
   const int kpad = hsk_next_pow2((int)k);
-  k_topk_rows<int64_t><<<(unsigned)rows, 256, 0, (hipStream_t)stream_>>>(logits, ld, (int)cols, (int)k, kpad, 0ll,
-                                                                          out_vals, out_idx);
+  if (cols > 256 * 48 && cols <= 256 * 64)
+    k_topk_rows_wide<int64_t><<<(unsigned)rows, 256, 0, (hipStream_t)stream_>>>(logits, ld, (int)cols, (int)k, kpad, 0ll,
+                                                                                 out_vals, out_idx);
+  else
+    k_topk_rows<int64_t><<<(unsigned)rows, 256, 0, (hipStream_t)stream_>>>(logits, ld, (int)cols, (int)k, kpad, 0ll,
+                                                                            out_vals, out_idx);
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
