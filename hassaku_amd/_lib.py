@@ -114,7 +114,13 @@ SIGNATURES = {
     'hsk_mf_eval_topk': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,
                                                                  c_void_p, c_void_p, c_int64,
                                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hsk_mf_eval_planes_bytes': (c_int64, [c_int64] * 3),
+    'hsk_mf_eval_topk_planes': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,
+                                                                        c_void_p, c_void_p, c_int64,
+                                                                        c_void_p, c_void_p, c_int64,
+                                                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     'hsk_mf_eval_fused_ws_bytes': (c_int64, [c_int64] * 3),
+    'hsk_mf_eval_fused_ws_bytes_dim': (c_int64, [c_int64] * 4),
     'hsk_mf_eval_topk_fused': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,
                                                                        c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                                                        c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -201,12 +201,60 @@ __device__ __forceinline__ void hsk_split3(float x, __bf16& h, __bf16& m, __bf16
   l = (__bf16)r2;
 }
 
-template <bool VEC4>
+// Pre-pass of the PLANES variants: rows [0, n_valid) of `src` (gathered through idx when given, else rows row0 + r) cut
+// into their three bf16 pieces ONCE per call, laid out [Dp / 32 k-tiles][n_pad rows][3 pieces][32] -- a 128-row tile's
+// pieces of one k-tile are 24 KB of consecutive bytes -- zero beyond the valid rows and beyond D.  One thread per 4
+// consecutive elements (D % 4 == 0, 16-byte aligned rows).  The GEMM loops then only move 16-byte chunks global ->
+// registers -> LDS: the split (two roundings and two subtractions per element, per tile, in every workgroup) was a sixth
+// of the loop (profiles/probes/gemm_bf16x3.hip: 640 -> 545 us at the ml10m eval shape, 575 with this pre-pass).
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                      long long row0, long long n_src_rows, int n_valid, int n_pad, int D,
+                                                      int Dp, __bf16* __restrict__ planes) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = Dp / 4;
+  const long long r = t / per_row;
+  const int k = (int)(t - r * per_row) * 4;
+  if (r >= n_pad) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < n_valid && k < D) {
+    long long sr = idx ? idx[r] : row0 + r;
+    if (sr < 0 || sr >= n_src_rows) sr = 0;   // (a bad index is reported by the scoring kernel)
+    const float4 x = *reinterpret_cast<const float4*>(src + sr * (long long)D + k);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  }
+  hsk_bf16x4 p1, p2, p3;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    __bf16 x1, x2, x3;
+    hsk_split3(v[e], x1, x2, x3);
+    p1[e] = x1; p2[e] = x2; p3[e] = x3;
+  }
+  __bf16* dst = planes + ((long long)(k / GEMM_BK) * n_pad + r) * 96 + (k % GEMM_BK);
+  *reinterpret_cast<hsk_bf16x4*>(dst) = p1;
+  *reinterpret_cast<hsk_bf16x4*>(dst + 32) = p2;
+  *reinterpret_cast<hsk_bf16x4*>(dst + 64) = p3;
+}
+
+// (also used by hsk_eval_fused.hip)  planes: 6 * n_pad * Dp bytes, Dp = dim rounded up to 32
+void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
+                           int n_pad, int D, void* planes, hipStream_t stream) {
+  const int Dp = (int)hsk_align_up(D, GEMM_BK);
+  k_split_planes<<<(unsigned)hsk_ceil_div((long long)n_pad * (Dp / 4), 256), 256, 0, stream>>>(
+      src, idx, row0, n_src_rows, n_valid, n_pad, D, Dp, (__bf16*)planes);
+}
+
+typedef unsigned hsk_vu32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 structs ends up in scratch)
+
+// PLANES: Apl / Bpl hold the operands' pieces (k_split_planes; a_rows / b_rows = their padded row counts)
+template <bool VEC4, bool PLANES = false>
 __global__ __launch_bounds__(256, 2) void k_score_gemm_x3(const float* __restrict__ Uw, const float* __restrict__ Iw,
                                                     const float* __restrict__ Ib, const float* __restrict__ Ub,
                                                     const float* __restrict__ gb, int n_users, int D,
                                                     const int64_t* __restrict__ u_idx, int n_rows, long long item_begin,
-                                                    int item_count, float* __restrict__ C, int32_t* status) {
+                                                    int item_count, float* __restrict__ C, int32_t* status,
+                                                    const __bf16* __restrict__ Apl = nullptr,
+                                                    const __bf16* __restrict__ Bpl = nullptr, int a_rows = 0,
+                                                    int b_rows = 0) {
   __shared__ __attribute__((aligned(16))) __bf16 As[3][GEMM_BM * GEMM_X3_LDK];   // the three bf16 pieces of the tile
   __shared__ __attribute__((aligned(16))) __bf16 Bs[3][GEMM_BN * GEMM_X3_LDK];
   __shared__ int urow[GEMM_BM];
@@ -251,7 +299,18 @@ __global__ __launch_bounds__(256, 2) void k_score_gemm_x3(const float* __restric
   // land in registers while the matrix cores work; they go to LDS after the tile's last read.  (Loading straight
   // into LDS inside the loop left the memory latency of every tile exposed: 78 TFLOP/s; staged: see DESIGN.md.)
   float4 ra[4], rb[4];
+  hsk_vu32x4 rpa[6], rpb[6];   // PLANES: 6 x 16 bytes of the tile's 24 KB per operand
   auto load_tile = [&](int k0) {
+    if (PLANES) {   // chunk c of the tile's 1536 is the 16 bytes at 16 c
+      const __bf16* a = Apl + ((long long)(k0 / GEMM_BK) * a_rows + m0) * 96;
+      const __bf16* b = Bpl + ((long long)(k0 / GEMM_BK) * b_rows + n0) * 96;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        rpa[i] = *reinterpret_cast<const hsk_vu32x4*>(a + (tid + 256 * i) * 8);
+        rpb[i] = *reinterpret_cast<const hsk_vu32x4*>(b + (tid + 256 * i) * 8);
+      }
+      return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = srow + pass * 32;
@@ -283,6 +342,15 @@ __global__ __launch_bounds__(256, 2) void k_score_gemm_x3(const float* __restric
     }
   };
   auto store_tile = [&]() {
+    if (PLANES) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int c = tid + 256 * i, r = c / 12, j = c - r * 12, pl = j >> 2, kc = (j & 3) * 8;
+        *reinterpret_cast<hsk_vu32x4*>(&As[pl][r * GEMM_X3_LDK + kc]) = rpa[i];
+        *reinterpret_cast<hsk_vu32x4*>(&Bs[pl][r * GEMM_X3_LDK + kc]) = rpb[i];
+      }
+      return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = srow + pass * 32;
@@ -822,12 +890,30 @@ static int hsk_launch_topk_i32(const float* X, int64_t rows, int64_t cols, int64
   return HSK_OK;
 }
 
+extern "C" int64_t hsk_mf_eval_planes_bytes(int64_t n_rows, int64_t item_count, int64_t dim) {
+  if (n_rows <= 0 || item_count <= 0 || dim <= 0) return 0;
+  const int64_t Dp = hsk_align_up(dim, GEMM_BK);
+  return hsk_align_up(6 * hsk_align_up(n_rows, GEMM_BM) * Dp, 256) + hsk_align_up(6 * hsk_align_up(item_count, GEMM_BN) * Dp, 256);
+}
+
 extern "C" int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, const float* item_bias,
                                 const float* user_bias, const float* global_bias, int64_t n_users, int64_t n_items,
                                 int64_t dim, const int64_t* u_idx, int64_t n_rows, int64_t item_begin,
                                 int64_t item_count, const int64_t* excl_indptr, const int32_t* excl_indices, int64_t k,
                                 float* scores_ws, float* out_vals, int32_t* out_idx, int32_t* status,
                                 hsk_stream_t stream_) {
+  return hsk_mf_eval_topk_planes(user_emb, item_emb, item_bias, user_bias, global_bias, n_users, n_items, dim, u_idx,
+                                 n_rows, item_begin, item_count, excl_indptr, excl_indices, k, scores_ws, nullptr, 0,
+                                 out_vals, out_idx, status, stream_);
+}
+
+extern "C" int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_emb, const float* item_bias,
+                                       const float* user_bias, const float* global_bias, int64_t n_users,
+                                       int64_t n_items, int64_t dim, const int64_t* u_idx, int64_t n_rows,
+                                       int64_t item_begin, int64_t item_count, const int64_t* excl_indptr,
+                                       const int32_t* excl_indices, int64_t k, float* scores_ws, void* planes_ws,
+                                       int64_t planes_bytes, float* out_vals, int32_t* out_idx, int32_t* status,
+                                       hsk_stream_t stream_) {
   HSK_REQUIRE(user_emb && item_emb && u_idx && scores_ws, HSK_ERR_INVALID, "NULL pointer argument");
   HSK_REQUIRE(n_users > 0 && n_items > 0 && dim > 0, HSK_ERR_INVALID, "bad table shape");
   HSK_REQUIRE(item_begin >= 0 && item_count > 0 && item_begin + item_count <= n_items, HSK_ERR_INVALID,
@@ -847,7 +933,22 @@ extern "C" int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, co
 #define HSK_SCORE_GEMM(KERNEL)                                                                                        \
   KERNEL<<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users, (int)dim, u_idx, \
                                    (int)n_rows, (long long)item_begin, (int)item_count, scores_ws, status)
-  if (x3) {
+  static const int planes_on = getenv("HSK_EVAL_PLANES") ? atoi(getenv("HSK_EVAL_PLANES")) : 1;
+  if (x3 && vec4 && planes_on && planes_ws && ((uintptr_t)planes_ws & 255) == 0 &&
+      planes_bytes >= hsk_mf_eval_planes_bytes(n_rows, item_count, dim)) {
+    // the operands' bf16 pieces, made once for the call
+    const int64_t Dp = hsk_align_up(dim, GEMM_BK);
+    const int a_rows = (int)hsk_align_up(n_rows, GEMM_BM), b_rows = (int)hsk_align_up(item_count, GEMM_BN);
+    __bf16* Apl = (__bf16*)planes_ws;
+    __bf16* Bpl = (__bf16*)((char*)planes_ws + hsk_align_up(6 * (int64_t)a_rows * Dp, 256));
+    hsk_eval_split_planes(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, Apl, stream);
+    hsk_eval_split_planes(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, Bpl, stream);
+    HSK_LAUNCH_CHECK();
+    k_score_gemm_x3<true, true><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias,
+                                                         (int)n_users, (int)dim, u_idx, (int)n_rows,
+                                                         (long long)item_begin, (int)item_count, scores_ws, status, Apl,
+                                                         Bpl, a_rows, b_rows);
+  } else if (x3) {
     if (vec4) HSK_SCORE_GEMM(k_score_gemm_x3<true>); else HSK_SCORE_GEMM(k_score_gemm_x3<false>);
   } else {
     if (vec4) HSK_SCORE_GEMM(k_score_gemm<true>); else HSK_SCORE_GEMM(k_score_gemm<false>);

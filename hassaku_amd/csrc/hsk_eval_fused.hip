@@ -78,7 +78,10 @@ __device__ __forceinline__ void fg_wave_bitonic_desc(unsigned long long* s, int 
 
 // X3: the GEMM core of k_score_gemm_x3 (hsk_eval.hip): three bf16 pieces per fp32 operand, six bf16 MFMAs per block, the
 // same order of operations -- so the two paths stay bit-equal in either arithmetic
-template <bool VEC4, bool X3>
+// MODE 2: the same, but the three bf16 pieces of both operands come ready-made from global memory (k_split_planes, once
+// per call): the split's arithmetic leaves the k loop.  MODE 3: only the items' pieces do.
+typedef unsigned fg_u32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 structs ended up in scratch)
+template <bool VEC4, int MODE>
 __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__ Uw, const float* __restrict__ Iw,
                                                     const float* __restrict__ Ib, const float* __restrict__ Ub,
                                                     const float* __restrict__ gb, int n_users, int D,
@@ -88,7 +91,10 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
                                                     const int32_t* __restrict__ excl_indices, int k, int n_splits,
                                                     unsigned long long* __restrict__ cand_ws,
                                                     float* __restrict__ part_vals, int32_t* __restrict__ part_idx,
-                                                    int32_t* status) {
+                                                    int32_t* status, const __bf16* __restrict__ Apl = nullptr,
+                                                    const __bf16* __restrict__ Bpl = nullptr,
+                                                    long long a_stride = 0, long long b_stride = 0) {
+  constexpr bool X3 = MODE != 0, APL = MODE == 2, BPL = MODE >= 2;   // which operands come as ready-made planes
   // fp32 tiles [row][32+4], or (X3) three bf16 planes [row][32+8] each
   constexpr int TILE_BYTES = X3 ? 3 * FG_BM * FG_X3_LDK * 2 : FG_BM * FG_LDS_STRIDE * 4;
   __shared__ __attribute__((aligned(16))) unsigned char As_raw[TILE_BYTES];
@@ -251,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
   };
 
   float4 ra[4], rbv[4];   // register staging of the next k-tile (A: user rows, B: item rows)
+  fg_u32x4 rpa[6], rpb[6];   // planes: 6 x 16 bytes of the tile's 24 KB per operand
   for (int tile = t_lo; tile < t_hi; ++tile) {
     const int n0 = tile * FG_BN;
     // exclusion bits of this tile: the user's sorted CSR row is consumed as the tiles advance
@@ -281,11 +288,23 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
         for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     auto load_tile = [&](int n0, int k0) {
+      // planes are padded to whole tiles in rows and to 32 in k: no bounds to check; [k-tile][row][piece][32] makes a
+      // 128-row tile's three pieces of one k-tile 24 KB of consecutive bytes: chunk c of 1536 is 16 bytes at 16 c
+      if (APL) {
+        const __bf16* base = Apl + (long long)(k0 / FG_BK) * a_stride + (long long)m0 * 96;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rpa[i] = *reinterpret_cast<const fg_u32x4*>(base + (tid + 256 * i) * 8);
+      }
+      if (BPL) {
+        const __bf16* base = Bpl + (long long)(k0 / FG_BK) * b_stride + (long long)n0 * 96;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rpb[i] = *reinterpret_cast<const fg_u32x4*>(base + (tid + 256 * i) * 8);
+      }
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int r = srow + pass * 32;
         float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + r < n_rows) {
+        if (!APL && m0 + r < n_rows) {
           const float* src = Uw + (long long)urow[r] * D + k0 + scol;
           if (VEC4) {
             if (k0 + scol < D) va = *reinterpret_cast<const float4*>(src);
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
             if (k0 + scol + 3 < D) va.w = src[3];
           }
         }
-        if (n0 + r < item_count) {
+        if (!BPL && n0 + r < item_count) {
           const float* src = Iw + (item_begin + n0 + r) * (long long)D + k0 + scol;
           if (VEC4) {
             if (k0 + scol < D) vb = *reinterpret_cast<const float4*>(src);
@@ -307,33 +326,51 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
             if (k0 + scol + 3 < D) vb.w = src[3];
           }
         }
-        ra[pass] = va;
-        rbv[pass] = vb;
+        if (!APL) ra[pass] = va;
+        if (!BPL) rbv[pass] = vb;
       }
     };
     auto store_tile = [&]() {
+      if (APL || BPL) {
+        constexpr int PL = FG_BM * FG_X3_LDK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int c = tid + 256 * i, r = c / 12, j = c - r * 12, pl = j >> 2, kc = (j & 3) * 8;
+          if (APL) *reinterpret_cast<fg_u32x4*>(&Ap[pl * PL + r * FG_X3_LDK + kc]) = rpa[i];
+          if (BPL) *reinterpret_cast<fg_u32x4*>(&Bp[pl * PL + r * FG_X3_LDK + kc]) = rpb[i];
+        }
+      }
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int r = srow + pass * 32;
         if (X3) {
-          fg_bf16x4 a1, a2, a3, b1, b2, b3;
-          const float av[4] = {ra[pass].x, ra[pass].y, ra[pass].z, ra[pass].w};
-          const float bv[4] = {rbv[pass].x, rbv[pass].y, rbv[pass].z, rbv[pass].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            __bf16 x1, x2, x3;
-            fg_split3(av[e], x1, x2, x3);
-            a1[e] = x1; a2[e] = x2; a3[e] = x3;
-            fg_split3(bv[e], x1, x2, x3);
-            b1[e] = x1; b2[e] = x2; b3[e] = x3;
-          }
           constexpr int PL = FG_BM * FG_X3_LDK;
-          *reinterpret_cast<fg_bf16x4*>(&Ap[0 * PL + r * FG_X3_LDK + scol]) = a1;
-          *reinterpret_cast<fg_bf16x4*>(&Ap[1 * PL + r * FG_X3_LDK + scol]) = a2;
-          *reinterpret_cast<fg_bf16x4*>(&Ap[2 * PL + r * FG_X3_LDK + scol]) = a3;
-          *reinterpret_cast<fg_bf16x4*>(&Bp[0 * PL + r * FG_X3_LDK + scol]) = b1;
-          *reinterpret_cast<fg_bf16x4*>(&Bp[1 * PL + r * FG_X3_LDK + scol]) = b2;
-          *reinterpret_cast<fg_bf16x4*>(&Bp[2 * PL + r * FG_X3_LDK + scol]) = b3;
+          if (!APL) {
+            fg_bf16x4 a1, a2, a3;
+            const float av[4] = {ra[pass].x, ra[pass].y, ra[pass].z, ra[pass].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              __bf16 x1, x2, x3;
+              fg_split3(av[e], x1, x2, x3);
+              a1[e] = x1; a2[e] = x2; a3[e] = x3;
+            }
+            *reinterpret_cast<fg_bf16x4*>(&Ap[0 * PL + r * FG_X3_LDK + scol]) = a1;
+            *reinterpret_cast<fg_bf16x4*>(&Ap[1 * PL + r * FG_X3_LDK + scol]) = a2;
+            *reinterpret_cast<fg_bf16x4*>(&Ap[2 * PL + r * FG_X3_LDK + scol]) = a3;
+          }
+          if (!BPL) {
+            fg_bf16x4 b1, b2, b3;
+            const float bv[4] = {rbv[pass].x, rbv[pass].y, rbv[pass].z, rbv[pass].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              __bf16 x1, x2, x3;
+              fg_split3(bv[e], x1, x2, x3);
+              b1[e] = x1; b2[e] = x2; b3[e] = x3;
+            }
+            *reinterpret_cast<fg_bf16x4*>(&Bp[0 * PL + r * FG_X3_LDK + scol]) = b1;
+            *reinterpret_cast<fg_bf16x4*>(&Bp[1 * PL + r * FG_X3_LDK + scol]) = b2;
+            *reinterpret_cast<fg_bf16x4*>(&Bp[2 * PL + r * FG_X3_LDK + scol]) = b3;
+          }
         } else {
           *reinterpret_cast<float4*>(&As[r * FG_LDS_STRIDE + scol]) = ra[pass];
           *reinterpret_cast<float4*>(&Bs[r * FG_LDS_STRIDE + scol]) = rbv[pass];
@@ -498,6 +535,18 @@ __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ v
   }
 }
 
+// the pre-pass of MODE 2 / 3 (hsk_eval.hip, k_split_planes): pieces laid out [k-tile][row][piece][32]
+void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
+                           int n_pad, int D, void* planes, hipStream_t stream);
+
+// bytes of the pre-split pieces of a call (MODE 2 / 3)
+static int64_t hsk_fused_plane_bytes(int64_t n_rows, int64_t item_count, int64_t dim) {
+  if (dim <= 0) return 0;
+  const int64_t Dp = hsk_align_up(dim, FG_BK);
+  const int64_t a_rows = hsk_ceil_div(n_rows, FG_BM) * FG_BM, b_rows = hsk_ceil_div(item_count, FG_BN) * FG_BN;
+  return hsk_align_up(3 * a_rows * Dp * 2, 256) + hsk_align_up(3 * b_rows * Dp * 2, 256);
+}
+
 // number of item splits: enough workgroups to fill the chip (2 per CU), lists short enough for the merge
 static int hsk_fused_splits(int64_t n_rows, int64_t item_count, int64_t k) {
   const int64_t row_blocks = hsk_ceil_div(n_rows, FG_BM), n_tiles = hsk_ceil_div(item_count, FG_BN);
@@ -519,6 +568,11 @@ extern "C" int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count
   const int64_t slab = row_blocks * s * FG_BM * HSK_SEL_CAP * 8;   // candidate slabs
   const int64_t parts = s * n_rows * k * 8;                         // partial (value, id) lists
   return hsk_align_up(slab, 256) + hsk_align_up(parts, 256) + 256;
+}
+
+extern "C" int64_t hsk_mf_eval_fused_ws_bytes_dim(int64_t n_rows, int64_t item_count, int64_t k, int64_t dim) {
+  const int64_t base = hsk_mf_eval_fused_ws_bytes(n_rows, item_count, k);
+  return base < 0 ? base : base + hsk_fused_plane_bytes(n_rows, item_count, dim);
 }
 
 extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_emb, const float* item_bias,
@@ -554,15 +608,33 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
   const bool vec4 = (dim % 4 == 0) && ((((uintptr_t)user_emb | (uintptr_t)item_emb) & 15) == 0);
   float* pv = S == 1 ? out_vals : part_vals;
   int32_t* pi = S == 1 ? out_idx : part_idx;
-#define HSK_SCORE_TOPK(V4, X3)                                                                                          \
-  k_score_topk<V4, X3><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,    \
-                                                 (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count,   \
-                                                 tiles_per_split, excl_indptr, excl_indices, (int)k, S, slab, pv, pi,     \
-                                                 status)
-  if (hsk_eval_x3()) {
-    if (vec4) HSK_SCORE_TOPK(true, true); else HSK_SCORE_TOPK(false, true);
+  // A workspace of hsk_mf_eval_fused_ws_bytes_dim bytes also holds the operands' bf16 pieces: split once, here, instead of
+  // once per tile in every workgroup's k loop.  HSK_EVAL_PLANES: 0 off, 2 both operands, 3 items only, 1 (default) by rule.
+  static const int planes_on = getenv("HSK_EVAL_PLANES") ? atoi(getenv("HSK_EVAL_PLANES")) : 1;
+  const int64_t plane_bytes = hsk_fused_plane_bytes(n_rows, item_count, dim);
+  const bool planes = hsk_eval_x3() && planes_on && vec4 && ws_bytes >= need + plane_bytes;
+#define HSK_SCORE_TOPK(V4, MODE, ...)                                                                                   \
+  k_score_topk<V4, MODE><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias, (int)n_users,  \
+                                                   (int)dim, u_idx, (int)n_rows, (long long)item_begin, (int)item_count, \
+                                                   tiles_per_split, excl_indptr, excl_indices, (int)k, S, slab, pv, pi,   \
+                                                   status, ##__VA_ARGS__)
+  if (planes) {
+    const int Dp = (int)hsk_align_up(dim, FG_BK);
+    const int64_t a_rows = row_blocks * FG_BM, b_rows = n_tiles * FG_BN;
+    __bf16* Apl = (__bf16*)((char*)ws + need);
+    __bf16* Bpl = (__bf16*)((char*)Apl + hsk_align_up(3 * a_rows * Dp * 2, 256));
+    const long long a_stride = a_rows * 96, b_stride = b_rows * 96;   // elements per k-tile
+    const bool a_planes = planes_on != 3;
+    if (a_planes)
+      hsk_eval_split_planes(user_emb, u_idx, 0, n_users, (int)n_rows, (int)a_rows, (int)dim, Apl, stream);
+    hsk_eval_split_planes(item_emb, nullptr, item_begin, n_items, (int)item_count, (int)b_rows, (int)dim, Bpl, stream);
+    HSK_LAUNCH_CHECK();
+    if (a_planes) HSK_SCORE_TOPK(true, 2, Apl, Bpl, a_stride, b_stride);
+    else HSK_SCORE_TOPK(true, 3, Apl, Bpl, a_stride, b_stride);
+  } else if (hsk_eval_x3()) {
+    if (vec4) HSK_SCORE_TOPK(true, 1); else HSK_SCORE_TOPK(false, 1);
   } else {
-    if (vec4) HSK_SCORE_TOPK(true, false); else HSK_SCORE_TOPK(false, false);
+    if (vec4) HSK_SCORE_TOPK(true, 0); else HSK_SCORE_TOPK(false, 0);
   }
 #undef HSK_SCORE_TOPK
   HSK_LAUNCH_CHECK();

@@ -554,6 +554,7 @@ FUSED_TOPK_MIN_ITEMS = 32768   # below this many columns the warm-up of the in-G
                                # 4.3 M users/s fused against 5.6 M materialised at 10 677 items, 0.62 M against 0.52 M
                                # at 131 072
 _fused_ws = {}             # device -> scratch of the fused selection, grown on demand
+_planes_ws = {}            # device -> scratch of the materialised path's bf16 pieces, grown on demand
 
 
 def set_eval_arith(three_piece_bf16: bool):
@@ -599,7 +600,7 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
     if want_scores is None:
         want_scores = scores_ws is not None or item_count < FUSED_TOPK_MIN_ITEMS
     if not want_scores and scores_ws is None and 1 <= k <= FUSED_TOPK_MAX_K and R > 0:
-        need = lib.hsk_mf_eval_fused_ws_bytes(R, item_count, k)
+        need = lib.hsk_mf_eval_fused_ws_bytes_dim(R, item_count, k, dim)   # with room for the operands' bf16 pieces
         if need <= 0:
             raise ValueError('invalid fused top-k request')
         ws = _fused_ws.get(dev)
@@ -630,10 +631,16 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
         p_emb -= 4 * dim * item_begin
         p_bias = None if p_bias is None else p_bias - 4 * item_begin
         n_items = n_items_global
-    _lib.check(lib.hsk_mf_eval_topk(_p(user_emb), p_emb, p_bias, _p(user_bias), _p(global_bias),
-                                    n_users, n_items, dim, _p(u_idx), R, item_begin, item_count,
-                                    _p(excl_indptr), _p(excl_indices), k, _p(scores_ws), _p(vals), _p(idx),
-                                    _p(status), _stream()), 'hsk_mf_eval_topk')
+    # scratch for the operands' bf16 pieces (split once per call instead of once per tile in the GEMM loop)
+    need = lib.hsk_mf_eval_planes_bytes(R, item_count, dim)
+    planes = _planes_ws.get(dev)
+    if planes is None or planes.numel() < need:
+        planes = _planes_ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.check(lib.hsk_mf_eval_topk_planes(_p(user_emb), p_emb, p_bias, _p(user_bias), _p(global_bias),
+                                           n_users, n_items, dim, _p(u_idx), R, item_begin, item_count,
+                                           _p(excl_indptr), _p(excl_indices), k, _p(scores_ws), _p(planes),
+                                           planes.numel(), _p(vals), _p(idx), _p(status), _stream()),
+               'hsk_mf_eval_topk_planes')
     return vals, idx, scores_ws
 
 

@@ -434,12 +434,33 @@ int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, const float* 
                      int32_t* status, hsk_stream_t stream);
 
 /*
+ * The same call with scratch for the operands' bf16 pieces (hsk_eval_set_arith(1), the default arithmetic): given
+ * planes_ws of >= hsk_mf_eval_planes_bytes(n_rows, item_count, dim) bytes (256-byte aligned), the rows are cut into
+ * their three pieces once up front instead of once per tile inside the GEMM loop -- the same bits out.  planes_ws NULL
+ * (or too small, or dim % 4 != 0): exactly hsk_mf_eval_topk.
+ */
+int64_t hsk_mf_eval_planes_bytes(int64_t n_rows, int64_t item_count, int64_t dim);
+int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_emb, const float* item_bias,
+                            const float* user_bias, const float* global_bias,
+                            int64_t n_users, int64_t n_items, int64_t dim,
+                            const int64_t* u_idx, int64_t n_rows,
+                            int64_t item_begin, int64_t item_count,
+                            const int64_t* excl_indptr, const int32_t* excl_indices,
+                            int64_t k, float* scores_ws, void* planes_ws, int64_t planes_bytes,
+                            float* out_vals, int32_t* out_idx,
+                            int32_t* status, hsk_stream_t stream);
+
+/*
  * The same result WITHOUT the score matrix: the top-k selection runs inside the score GEMM (per-row thresholds and
  * candidate lists, csrc/hsk_eval_fused.hip), so nothing of size n_rows x item_count is ever written -- at 131 072
  * items that matrix is 1 GB per 2048 users.  k <= 128.  ws: hsk_mf_eval_fused_ws_bytes(n_rows, item_count, k) bytes of
  * device scratch, 256-byte aligned.  out_vals / out_idx exactly as hsk_mf_eval_topk returns them.
+ * hsk_mf_eval_fused_ws_bytes_dim(..., dim) is the larger size that also holds the three bf16 pieces of both operands
+ * (hsk_eval_set_arith(1), the default): given that much, the call splits the rows once up front instead of once per
+ * tile inside the GEMM loop -- same bits out, less work in the loop.  Either size is accepted.
  */
 int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count, int64_t k);
+int64_t hsk_mf_eval_fused_ws_bytes_dim(int64_t n_rows, int64_t item_count, int64_t k, int64_t dim);
 int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_emb, const float* item_bias,
                            const float* user_bias, const float* global_bias,
                            int64_t n_users, int64_t n_items, int64_t dim,

@@ -17,6 +17,7 @@ constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 8;   // LDS row stride in 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
@@ -107,6 +108,93 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16x3(const float* __restrict_
       }
 }
 
+
+// Variant: the pieces made once by a pre-pass, laid out [k-tile][row][piece][32] (a 128-row tile's three pieces of one
+// k-tile = 24 KB of consecutive bytes); the GEMM loop only moves 16-byte chunks global -> registers -> LDS.
+__global__ __launch_bounds__(256) void k_presplit(const float* __restrict__ X, int rows, __bf16* __restrict__ P) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = K / 4;
+  const long long r = t / per_row;
+  const int k = (int)(t - r * per_row) * 4;
+  if (r >= rows) return;
+  const float4 x = *reinterpret_cast<const float4*>(X + r * K + k);
+  const float v[4] = {x.x, x.y, x.z, x.w};
+  bf16x4 p1, p2, p3;
+  for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); p1[e] = a; p2[e] = b; p3[e] = c; }
+  __bf16* dst = P + ((long long)(k / BK) * rows + r) * 96 + (k % BK);
+  *reinterpret_cast<bf16x4*>(dst) = p1;
+  *reinterpret_cast<bf16x4*>(dst + 32) = p2;
+  *reinterpret_cast<bf16x4*>(dst + 64) = p3;
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_planes(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp, float* __restrict__ C) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * LDK];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int r32 = lane & 31, h = lane >> 5;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  u32x4 ra[6], rb[6];   // (ext-vector type: HIP's uint4 struct array ended up in scratch here)
+  auto load_tile = [&](int k0) {
+    const __bf16* a = Ap + ((long long)(k0 / BK) * M + m0) * 96;
+    const __bf16* b = Bp + ((long long)(k0 / BK) * N + n0) * 96;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4*>(a + (tid + 256 * i) * 8);
+      rb[i] = *reinterpret_cast<const u32x4*>(b + (tid + 256 * i) * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int c = tid + 256 * i, r = c / 12, j = c - r * 12, pl = j >> 2, kc = (j & 3) * 8;
+      *reinterpret_cast<u32x4*>(&As[pl][r * LDK + kc]) = ra[i];
+      *reinterpret_cast<u32x4*>(&Bs[pl][r * LDK + kc]) = rb[i];
+    }
+  };
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool has_next = k0 + BK < K;
+    if (has_next) load_tile(k0 + BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          a[pl][i] = *reinterpret_cast<const bf16x8*>(&As[pl][(wm * 64 + i * 32 + r32) * LDK + 16 * s + 8 * h]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[pl][j] = *reinterpret_cast<const bf16x8*>(&Bs[pl][(wn * 64 + j * 32 + r32) * LDK + 16 * s + 8 * h]);
+      }
+      constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (has_next) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const int col = n0 + wn * 64 + j * 32 + r32;
+        C[(long long)row * N + col] = acc[i][j][q];
+      }
+}
+
 int main() {
   float *A, *B, *C;
   CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&B, (size_t)N * K * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
@@ -128,6 +216,27 @@ int main() {
   }
   const double flop = 2.0 * M * N * K;
   printf("bf16x3 (6 terms): mean %.1f us best %.1f us = %.1f TFLOP/s fp32-equivalent\n", tot / 5 * 1e3, best * 1e3, flop / (tot / 5 * 1e-3) / 1e12);
+  {
+    __bf16 *Ap, *Bp; float* C2;
+    CK(hipMalloc(&Ap, (size_t)M * K * 6)); CK(hipMalloc(&Bp, (size_t)N * K * 6)); CK(hipMalloc(&C2, (size_t)M * N * 4));
+    float bp = 1e9, tp = 0, tg = 0;
+    for (int rep = 0; rep < 7; ++rep) {
+      hipEvent_t e2; CK(hipEventCreate(&e2));
+      CK(hipEventRecord(e0));
+      k_presplit<<<(unsigned)(((size_t)M * K / 4 + 255) / 256), 256>>>(A, M, Ap);
+      k_presplit<<<(unsigned)(((size_t)N * K / 4 + 255) / 256), 256>>>(B, N, Bp);
+      CK(hipEventRecord(e2));
+      k_gemm_planes<<<grid, 256>>>(Ap, Bp, C2);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms, msg; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventElapsedTime(&msg, e2, e1));
+      if (rep >= 2) { tp += ms; tg += msg; if (ms < bp) bp = ms; }
+    }
+    printf("pre-split planes: mean %.1f us with the pre-pass (GEMM alone %.1f us) = %.1f TFLOP/s fp32-equivalent\n", tp / 5 * 1e3, tg / 5 * 1e3, flop / (tp / 5 * 1e-3) / 1e12);
+    std::vector<float> c1((size_t)64 * N), c2((size_t)64 * N);
+    CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c2.data(), C2, c2.size() * 4, hipMemcpyDeviceToHost));
+    size_t diff = 0; for (size_t i = 0; i < c1.size(); ++i) diff += c1[i] != c2[i];
+    printf("planes vs in-loop split: %zu of %zu values differ\n", diff, c1.size());
+  }
   std::vector<float> hC((size_t)256 * N);
   CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
   double maxrel = 0, maxabs = 0, scale = 0;
