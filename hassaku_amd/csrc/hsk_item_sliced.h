@@ -201,6 +201,12 @@ __device__ __forceinline__ void hsk_item_row_body(const hsk_item_args& a, int bi
   hsk_row_load<V, NCH, FULL>(p, prow, lane, D);   // AdamW operands early: their latency hides under the gather
   hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
   hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  float pb = 0.f, mb = 0.f, vb = 0.f;   // the bias triple too (it used to be loaded after the reduction: a latency at the tail)
+  if (a.Ib && lane == 0) {
+    pb = a.Ib[i];
+    mb = a.mIb[i];
+    vb = a.vIb[i];
+  }
   hsk_row_zero(acc);
   float gb_lane = 0.f;
   for (int c0 = beg; c0 < end; c0 += 64) {
@@ -233,7 +239,6 @@ __device__ __forceinline__ void hsk_item_row_body(const hsk_item_args& a, int bi
   if (a.Ib) {
     const float gbias = hsk_wave_sum(gb_lane);
     if (lane == 0) {
-      float pb = a.Ib[i], mb = a.mIb[i], vb = a.vIb[i];
       hsk_adamw_update<GEN>(pb, mb, vb, gbias, c);
       a.Ib[i] = pb;
       a.mIb[i] = mb;

@@ -141,19 +141,36 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
 
   using Row = hsk_row<V, NCH>;
   const int* __restrict__ irow = it32 + (long long)b * K;
-  const int u = hsk_uniform_i(u32[b]);
-  const int i0 = hsk_uniform_i(irow[0]);
+  // Short rows (D <= 256) mean small tables and small batches: the kernel is a chain of memory latencies, so the loads are
+  // issued in two rounds instead of four -- (1) user id, positive and the first 64 item ids, (2) user row, positive's row,
+  // biases and the first R item rows.  (Long rows: the early item rows would cost the large-batch shapes a wave per SIMD.)
+  constexpr bool EARLY = NCH * V <= 4;
+  const int u_v = u32[b];
+  const int i0_v = irow[0];
+  int id_first = (EARLY && lane < min(64, K - 1)) ? irow[1 + lane] : -1;
+  const int u = hsk_uniform_i(u_v);
+  const int i0 = hsk_uniform_i(i0_v);
 
   Row ur, r0, acc;
   hsk_row_load<V, NCH, FULL>(ur, Uw + (long long)u * D, lane, D);
   hsk_row_load<V, NCH, FULL>(r0, Iw + (long long)i0 * D, lane, D);
+  const float bias0 = Ib ? Ib[i0] : 0.f;
+  float bias_first = 0.f;
+  Row bufA[R], bufB[R];
+  if (EARLY) {
+    if (id_first < 0) id_first = i0;
+    bias_first = Ib ? Ib[id_first] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r < K - 1) hsk_row_load<V, NCH, FULL>(bufA[r], Iw + (long long)hsk_readlane_i(id_first, r) * D, lane, D);
+  }
   if (lz.mU)
     hsk_user_row_current<V, NCH, FULL>(ur, u, b, B, D, lane, lz, true, hsk_uniform_i(lz.last_step[u]),
                                        hsk_uniform_i(lz.owner[u]));
   else if (lz.ucur)   // dense user updates: the rows are current; the item pass still reads them by batch position
     hsk_row_store<V, NCH, FULL>(ur, lz.ucur + (long long)b * D, lane, D);
   hsk_row_zero(acc);
-  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + (Ib ? Ib[i0] : 0.f);
+  const float s0 = hsk_wave_sum(hsk_row_dot_partial(ur, r0)) + bias0;
 
   float gsum = 0.f;    // BPR: sum over negatives of sigma(-x)/(B*N)   (wave-uniform)
   double lsum = 0.0;   // per-lane partial of the loss terms
@@ -162,15 +179,17 @@ __global__ __launch_bounds__(256) void k_fwd_ugrad(const float* __restrict__ Uw,
 
   for (int kc = 1; kc < K; kc += 64) {
     const int nr = min(64, K - kc);
-    const int myidx = (lane < nr) ? irow[kc + lane] : i0;
-    const float mybias = Ib ? Ib[myidx] : 0.f;
+    const bool first = EARLY && kc == 1;   // ids, biases and the first rows of this chunk are already on their way
+    const int myidx = first ? id_first : (lane < nr) ? irow[kc + lane] : i0;
+    const float mybias = first ? bias_first : Ib ? Ib[myidx] : 0.f;
     float gv = 0.f, xv = 0.f;
 
-    Row bufA[R], bufB[R];
     // prologue
+    if (!first) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (r < nr) hsk_row_load<V, NCH, FULL>(bufA[r], Iw + (long long)hsk_readlane_i(myidx, r) * D, lane, D);
+      for (int r = 0; r < R; ++r)
+        if (r < nr) hsk_row_load<V, NCH, FULL>(bufA[r], Iw + (long long)hsk_readlane_i(myidx, r) * D, lane, D);
+    }
 
     auto process = [&](Row(&buf)[R], int j) {
 #pragma unroll
