@@ -437,7 +437,16 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
     if (tile + 1 < t_hi) load_tile(n0 + FG_BN, 0);   // in flight during the epilogue and the compactions
     // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      // the 16 rows of this lane's accumulator registers: their thresholds in one burst of LDS reads (thr only changes in
+      // the compactions, behind the barrier below) -- read one by one in front of each compare they were 64 exposed LDS
+      // latencies per tile and wave.  Rows past n_rows: +inf, nothing passes.
+      float t[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rloc = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        t[q] = (m0 + rloc < n_rows) ? thr[rloc] : INFINITY;
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int cloc = wn * 64 + j * 32 + l32;
@@ -448,13 +457,12 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int rloc = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-          if (m0 + rloc >= n_rows) continue;
           float o = acc[i][j][q];
           if (Ub) o += ubias[rloc];   // reference order: += u_bias, += i_bias, += global_bias
           if (Ib) o += ib;
           if (gb) o += gbv;
-          // the common case ends here: one LDS read and one compare per score (NaN passes, as in torch.topk)
-          if (!(o < thr[rloc])) {
+          // the common case ends here: one compare per score (NaN passes, as in torch.topk)
+          if (!(o < t[q]) && m0 + rloc < n_rows) {
             if ((emask[rloc][cloc >> 5] >> (cloc & 31)) & 1u) o = -INFINITY;
             if (!(o < thr[rloc])) {
               const int slot = atomicAdd(&cnt[rloc], 1);
@@ -463,11 +471,17 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
           }
         }
       }
+    }
     __syncthreads();
     // rows that the next tile could overflow: compact now (wave w owns rows 32w .. 32w+31)
-    for (int rr = 0; rr < 32; ++rr) {
-      const int rloc = wave * 32 + rr;
-      if (cnt[rloc] > HSK_SEL_TRIG) compact_row(rloc);
+    {   // (one LDS read per lane and a ballot, not 32 reads in a row)
+      const int fill = (lane < 32) ? cnt[wave * 32 + lane] : 0;
+      unsigned long long due = __ballot(fill > HSK_SEL_TRIG);
+      while (due) {
+        const int rr = __builtin_ctzll(due);
+        due &= due - 1;
+        compact_row(wave * 32 + rr);
+      }
     }
     __syncthreads();
   }
