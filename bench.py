@@ -305,8 +305,8 @@ def run_eval(shape, device, comm=None, chunk=None, repeat=3):
     from hassaku_amd import hip_ops as ops
     from hassaku_amd.eval.eval import FullEvaluator
     U, I, D, npos = EVAL_SHAPES[shape]
-    if chunk is None:     # wide catalogue: top-k inside the GEMM, big chunks; narrow: materialised scores
-        chunk = 16384 if I >= ops.FUSED_TOPK_MIN_ITEMS else 8192
+    if chunk is None:     # (wide catalogue: top-k inside the GEMM; narrow: materialised scores, 0.7 GB of them per chunk at ml10m)
+        chunk = 16384
     torch.manual_seed(0)
     user_emb = torch.randn(U, D, device=device) * 0.05
     item_emb = torch.randn(I, D, device=device) * 0.05

@@ -123,10 +123,9 @@ def evaluate_recommender_algorithm(alg: RecommenderAlgorithm, eval_loader, evalu
             raise RuntimeError('SGDMatrixFactorization evaluates on the HIP device only; move the model with '
                                '.to("cuda") (conf device: cuda)')
         with torch.no_grad():
-            # wide catalogues select inside the GEMM (nothing of size chunk x n_items exists: the chunk only has to
-            # fill the chip); narrow ones materialise chunk x n_items scores
-            wide = dataset.n_items >= hip_ops.FUSED_TOPK_MIN_ITEMS
-            chunk = max(int(getattr(eval_loader, 'batch_size', 256) or 256), 16384 if wide else 4096)
+            # wide catalogues select inside the GEMM (nothing of size chunk x n_items exists); narrow ones (fewer than
+            # hip_ops.FUSED_TOPK_MIN_ITEMS columns) materialise chunk x n_items scores: at most 2 GB per chunk
+            chunk = max(int(getattr(eval_loader, 'batch_size', 256) or 256), 16384)
             _hip_mf_eval(alg, dataset, evaluator, dev, chunk)
     elif isinstance(alg, SGDBasedRecommenderAlgorithm) and hasattr(alg, 'lookup'):
         # the other SGD models: item representations once, then every user batch against them (eval/eval.py:237-248);
