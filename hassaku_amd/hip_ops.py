@@ -565,8 +565,10 @@ def set_eval_arith(three_piece_bf16: bool):
 
 def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k, excl_indptr=None, excl_indices=None,
                  item_begin=0, item_count=None, scores_ws=None, status=None, item_shard=False, n_items_global=None,
-                 want_scores=None):
+                 want_scores=None, presplit=True):
     """Top-k of one item shard's masked scores.  -> (vals [R,k] f32, idx [R,k] i32 global, scores or None).
+    presplit=False withholds the scratch for the operands' bf16 pieces: the GEMM then splits every tile in its loop
+    (same bits; the form the library falls back to by itself, kept reachable for the parity test).
     want_scores=False: the selection runs inside the score GEMM and the score matrix is never formed (scores = None).
     want_scores=True (or a `scores_ws` buffer, k == 0, k > 128): the [R, item_count] matrix is materialised and
     returned.  None (default): whichever is faster for the shard width (FUSED_TOPK_MIN_ITEMS); same results.
@@ -600,7 +602,10 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
     if want_scores is None:
         want_scores = scores_ws is not None or item_count < FUSED_TOPK_MIN_ITEMS
     if not want_scores and scores_ws is None and 1 <= k <= FUSED_TOPK_MAX_K and R > 0:
-        need = lib.hsk_mf_eval_fused_ws_bytes_dim(R, item_count, k, dim)   # with room for the operands' bf16 pieces
+        if presplit:
+            need = lib.hsk_mf_eval_fused_ws_bytes_dim(R, item_count, k, dim)   # with room for the operands' bf16 pieces
+        else:
+            need = lib.hsk_mf_eval_fused_ws_bytes(R, item_count, k)
         if need <= 0:
             raise ValueError('invalid fused top-k request')
         ws = _fused_ws.get(dev)
@@ -615,7 +620,8 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
             n_all = n_items_global
         _lib.check(lib.hsk_mf_eval_topk_fused(_p(user_emb), p_emb, p_bias, _p(user_bias), _p(global_bias), n_users,
                                               n_all, dim, _p(u_idx), R, item_begin, item_count, _p(excl_indptr),
-                                              _p(excl_indices), k, _p(ws), ws.numel(), _p(vals), _p(idx), _p(status),
+                                              _p(excl_indices), k, _p(ws), ws.numel() if presplit else need, _p(vals),
+                                              _p(idx), _p(status),
                                               _stream()), 'hsk_mf_eval_topk_fused')
         return vals, idx, None
     if scores_ws is None:
@@ -638,8 +644,9 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
         planes = _planes_ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
     _lib.check(lib.hsk_mf_eval_topk_planes(_p(user_emb), p_emb, p_bias, _p(user_bias), _p(global_bias),
                                            n_users, n_items, dim, _p(u_idx), R, item_begin, item_count,
-                                           _p(excl_indptr), _p(excl_indices), k, _p(scores_ws), _p(planes),
-                                           planes.numel(), _p(vals), _p(idx), _p(status), _stream()),
+                                           _p(excl_indptr), _p(excl_indices), k, _p(scores_ws),
+                                           _p(planes) if presplit else None, planes.numel() if presplit else 0,
+                                           _p(vals), _p(idx), _p(status), _stream()),
                'hsk_mf_eval_topk_planes')
     return vals, idx, scores_ws
 

@@ -672,6 +672,34 @@ def test_fused_topk_equals_materialised_topk(ops, shape):
     _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross=True)
 
 
+@pytest.mark.parametrize('shape', [(300, 300, 5000, 512, 100), (257, 400, 1300, 128, 5), (64, 64, 129, 16, 100)])
+def test_presplit_operands_equal_in_loop_split(ops, shape):
+    """The score GEMMs fed from the pre-pass that cuts the operands into their bf16 pieces once per call
+    (hsk_mf_eval_topk_planes / a hsk_mf_eval_fused_ws_bytes_dim workspace) return the very bits of the form that splits
+    every tile in its loop (no scratch given): scores, top-k values, ids -- materialised and fused, whole catalogue and an
+    item range with a ragged last tile."""
+    R, n_users, n_items, D, k = shape
+    g = torch.Generator(device='cuda').manual_seed(11)
+    U = torch.randn(n_users, D, device='cuda', generator=g) * 0.3
+    I = torch.randn(n_items, D, device='cuda', generator=g) * 0.3
+    Ib = torch.randn(n_items, device='cuda', generator=g) * 0.1
+    rng = np.random.RandomState(3)
+    pairs = np.argwhere(rng.rand(n_users, n_items) < min(0.05, 200.0 / n_items))
+    e_ptr, e_idx = csr_from_pairs(pairs, n_users)
+    u = torch.from_numpy(rng.randint(0, n_users, size=R).astype(np.int64)).cuda()
+    for lo, cnt in ((0, n_items), (n_items // 3, n_items - n_items // 3 - 7)):
+        kk = min(k, cnt)
+        for want in (True, False):
+            a = ops.mf_eval_topk(U, I, Ib, None, None, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
+                                 want_scores=want, presplit=True)
+            b = ops.mf_eval_topk(U, I, Ib, None, None, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
+                                 want_scores=want, presplit=False)
+            assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), (shape, lo, want)
+            assert torch.equal(a[1], b[1]), (shape, lo, want)
+            if want:
+                assert torch.equal(a[2][:R * cnt].view(torch.int32), b[2][:R * cnt].view(torch.int32))
+
+
 def _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross):
     exact = not cross
 
