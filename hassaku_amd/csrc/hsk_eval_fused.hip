@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
           // the common case ends here: one compare per score (NaN passes, as in torch.topk)
           if (!(o < t[q]) && m0 + rloc < n_rows) {
             if ((emask[rloc][cloc >> 5] >> (cloc & 31)) & 1u) o = -INFINITY;
-            if (!(o < thr[rloc])) {
+            if (!(o < t[q])) {   // (t[q] == thr[rloc] for a valid row)
               const int slot = atomicAdd(&cnt[rloc], 1);
               cand[(long long)rloc * HSK_SEL_CAP + slot] = ((unsigned long long)fg_f2key(o) << 32) | nid;
             }
