@@ -44,7 +44,10 @@ int hsk_eval_x3();   // hsk_eval.hip: which arithmetic the score GEMMs use
 #endif
 #define HSK_SEL_KMAX 128           // k supported by the fused path
 #ifndef HSK_SEL_TRIG
-#define HSK_SEL_TRIG (HSK_SEL_CAP - FG_BN)   // a row is compacted when it holds more than this (<= CAP - 128)
+// a row is compacted when it holds more than this (<= CAP - 128, > KMAX).  Between two compactions the row's threshold is
+// stale and lets too much through; a compaction is a wave-wide radix select.  Measured at the lfm2b shape with the
+// bf16x3 core: 384: 895-902 k users/s, 320: 911-913, 256: 911-912, 192: 879-882
+#define HSK_SEL_TRIG 320
 #endif
 
 __device__ __forceinline__ uint32_t fg_f2key(float f) {
