@@ -67,7 +67,7 @@ def fwd_read_bytes(B, N, D):
 
 
 def pmc_traffic(kernel_prefix, workload):
-    """HBM-side traffic of one launch from the COMMITTED rocprofv3 PMC passes of this same command (tools_profile.sh;
+    """HBM-side traffic of one launch from the COMMITTED rocprofv3 PMC passes of this same command (tools/profile.sh;
     FETCH_SIZE and WRITE_SIZE are collected in separate runs and reported in KB).  On gfx950 FETCH_SIZE counts 64 B
     per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM): x2.  -> (bytes | None, source)."""
     d = PROFILE_DIR.get(workload)
@@ -217,6 +217,129 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     if all_stages:
         out['stage_us_per_step'] = {k: v[0] * 1e3 / max(v[1], 1) for k, v in timing.items()}
     del st
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: synthetic 100 M users x 10 M items, dim = 1024, neg_train = 200, 8 ranks, both tables sharded
+# ------------------------------------------------------------------------------------------------
+CFG5 = dict(U=100_000_000, I=10_000_000, D=1024, N=200, B=8192, world=8, share_rank=3)
+
+
+def run_cfg5(device, steps, warmup, comm=None):
+    """comm with 8 ranks: the job itself -- every rank generates the interactions on its device (csrc/hsk_synth.hip: a
+    pure function of the seed, no broadcast, no CSV), initialises ITS shards directly (no full table exists anywhere)
+    and steps the sharded path.  comm None: ONE RANK'S SHARE on this GPU -- rank 3 of 8 with its real state (12.5 M x
+    1024 user rows, items [3.75 M, 5 M), p/m/v = 169 GB, the 2e9 global interactions) and its real kernels; the
+    collectives are local stand-ins (dist.LoopbackComm: the peers' user rows are stand-in rows, their score / gradient
+    contributions are absent), so RCCL time is not in the figure."""
+    from hassaku_amd.data.synthetic import DeviceInteractions
+    from hassaku_amd.dist import LoopbackComm, ShardedBprMf, init_shard_tables
+    c5 = CFG5
+    U, I, D, N, B = c5['U'], c5['I'], c5['D'], c5['N'], c5['B']
+    share = comm is None
+    c = LoopbackComm(c5['world'], c5['share_rank']) if share else comm
+    W, r = c.world, c.rank
+    t_build = time.perf_counter()
+    # every rank must get through the build (190 GB of allocations) or none may enter the collectives of the steps
+    err = None
+    try:
+        need = 12.0 * D * (U / W + I / W) + 8.0 * (U + 1) + 8.5 * 20.0 * U + 4e9
+        free, _ = torch.cuda.mem_get_info(device)
+        if free < need:
+            raise RuntimeError(f'cfg5 needs ~{need / 1e9:.0f} GB of HBM per rank, {free / 1e9:.0f} GB free')
+        data = DeviceInteractions(U, I, device, seed=0)
+        tabs = init_shard_tables(r, W, U, I, D, device, seed=64)
+    except Exception as e:   # noqa: BLE001
+        err = e
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=device)
+    if not share:
+        ok = ok.float()
+        c.all_reduce(ok)
+    if int(ok.item()) != (1 if share else W):
+        raise RuntimeError(f'cfg5 build failed on rank {r}: {err}' if err is not None else 'cfg5 build failed on another rank')
+    st = ShardedBprMf(c, tabs['user_emb'], tabs['item_emb'], tabs['item_bias'], None, None, lr=LR, wd=WD, batch=B,
+                      n_neg=N, seed=64, inputs_are_shards=True, n_users=U, n_items=I, **data.device_arrays())
+    del tabs
+    if share:
+        st.rows_all.normal_(std=0.1 / D)          # the absent peers' user rows
+    G = W * B
+    order = data.random_order((warmup + steps + 1) * G, seed=64)
+    if not share:
+        c.broadcast(order, src=0)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    def run(n, first):
+        for s in range(n):
+            st.step_sampled(order, (first + s) * G, next_start=(first + s + 1) * G)
+
+    def fence():
+        c.barrier()
+        torch.cuda.synchronize()
+
+    run(warmup, 0)
+    fence()
+    st.check_status('cfg5 warm-up')
+    st.enable_timing(('fwd', 'item', 'user'), every=1)
+    fence()
+    t0 = time.perf_counter()
+    run(steps, warmup)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st.disable_timing()
+    timing = st.collect_timing()
+    if not share:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        c.all_reduce(t, op='max')
+        elapsed = float(t.item())
+    # the sweep of the lazily updated shards, timed on its own: it comes due every `cadence` steps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    st.flush()
+    e1.record()
+    torch.cuda.synchronize()
+    flush_ms = e0.elapsed_time(e1)
+    st.check_status('cfg5 timed region')
+    loss = st.last_loss()
+    offs, _, _ = st.last_batch()
+    kept = int(offs[G].item())
+    fu, fi = st.flush_cadence()
+    stage = {k: v[0] * 1e3 / max(v[1], 1) for k, v in timing.items()}
+    # k_shard_fwd: one user row per positive of the global batch (from the exchange buffer) + one item row per kept entry
+    by = 4 * D * (G + kept) + 8 * kept + 12 * G
+    fwd_us = stage.get('fwd')
+    roof = None
+    if fwd_us:
+        ach = by / (fwd_us * 1e-6) / 1e9
+        roof = {'bound': 'hbm', 'kernel': 'k_shard_fwd (per positive of the global batch: gather of the OWNED negatives\' item rows + scores + BPR + partial user-row gradient)',
+                'achieved': ach, 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'frac': ach / HBM_PEAK_GBS,
+                'frac_of_measured_hbm_gather_5750': ach / HBM_GATHER_GBS, 'traffic': None, 'avg_us': fwd_us,
+                'launches': int(timing['fwd'][1]), 'algorithmic_bytes_per_launch': by,
+                'item_shard_GB': 4.0 * D * st.item_emb.shape[0] / 1e9, 'kept_entries_per_step': kept}
+    ms = elapsed * 1e3 / steps
+    amort = (flush_ms / fu) if fu < (1 << 29) else 0.0
+    out = {'workload': f'configs[4]: synthetic U={U}, I={I} ({data.nnz} interactions generated on device), mf + bpr + adamw, '
+                       f'embedding_dim={D}, neg_train={N}, batch={B} per rank x {W} ranks'
+                       + (f'; THIS IS RANK {r}\'S SHARE ALONE on one GPU (collectives stubbed, peers absent)' if share else ''),
+           'n_gpus_of_the_job': W, 'ranks_running': 1 if share else W,
+           'ms_per_step': ms, 'ms_per_step_with_amortised_sweep': ms + amort, 'steps': steps, 'warmup': warmup,
+           'triplets_per_step_global': G * N, 'loss_last_step' + ('_local_share' if share else ''): loss,
+           'stage_us_per_step': stage, 'roofline': roof,
+           'lazy_sweep': {'cadence_steps_users': fu if fu < (1 << 29) else None,
+                          'cadence_steps_items': fi if fi < (1 << 29) else None, 'sweep_ms': flush_ms,
+                          'amortised_ms_per_step': amort},
+           'per_rank_GB': {'tables_and_moments': 12.0 * D * (st.user_emb.shape[0] + st.item_emb.shape[0]) / 1e9,
+                           'interactions': (8.0 * (U + 1) + 8.0 * data.nnz) / 1e9},
+           'user_slots_per_owner': st.capacity, 'entry_capacity': st.entry_cap, 'build_seconds': t_build}
+    if share:
+        out['value_rank_share'] = B * N / (ms + amort) * 1e3
+        out['unit'] = 'triplets/s handled by this rank (the job: x8 if the ranks overlap perfectly and RCCL hides)'
+    else:
+        out['value'] = G * N / (ms + amort) * 1e3
+        out['unit'] = 'triplets/s'
+    del st, data, order
     torch.cuda.empty_cache()
     return out
 
@@ -423,13 +546,24 @@ def cpu_baseline(headline, budget_s):
             'legs': legs}
 
 
+def guarded(fn, *a):
+    """An extra leg must not cost the line its headline: a failure is recorded, not raised."""
+    try:
+        return fn(*a)
+    except Exception as e:   # noqa: BLE001
+        torch.cuda.empty_cache()
+        return {'error': f'{type(e).__name__}: {e}'[:500]}
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='ml10m', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='ml10m', choices=sorted(WORKLOADS) + ['cfg5'],
+                    help="cfg5 = BASELINE configs[4] (100 M x 10 M, D=1024): the job itself with --gpus 8, one rank's "
+                         "share of it (rank 3 of 8, collectives stubbed) with --gpus 1")
     ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of CPU-baseline work on the headline workload (0 = skip every CPU leg)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' "
                     "stages collectives through the host and lets several ranks share one GPU: functional rehearsal only)")
@@ -472,6 +606,18 @@ def main():
             dist.init_process_group(args.backend)
         comm = Comm()
 
+    if args.workload == 'cfg5':
+        if world not in (1, CFG5['world']):
+            raise SystemExit('--workload cfg5 runs with --gpus 8 (the job) or --gpus 1 (one rank\'s share)')
+        x = run_cfg5(device, args.steps, args.warmup, comm if world > 1 else None)
+        out = {'workloads': {'cfg5' if world > 1 else 'cfg5_shard': x}}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if comm is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.eval_only:
         out = {'eval': {args.eval_only: run_eval(args.eval_only, device, comm)}}
         if rank == 0:
@@ -517,8 +663,12 @@ def main():
                     'steps_issued_as_replayed_graphs': 64 * x['graph_replays'],
                     'roofline': roofline_of(name, x)}
             out['eval'] = {s: run_eval(s, device) for s in ('ml10m', 'lfm2b')}
+            # BASELINE configs[4] needs 8 GPUs; what one GPU can show is one rank's full-size share of it
+            out['workloads']['cfg5_shard'] = guarded(run_cfg5, device, 12, 4)
         else:
             out['eval'] = {'lfm2b': run_eval('lfm2b', device, comm)}
+            if world == CFG5['world']:     # the one place the whole configs[4] job can run
+                out['workloads'] = {'cfg5': guarded(run_cfg5, device, 12, 4, comm)}
     if cpu is not None:
         out['cpu_baseline'] = cpu
     if rank == 0:

@@ -40,6 +40,7 @@ class HskBprmfState(ctypes.Structure):
         ('lazy_items', c_int32), ('graph_chunk', c_int32),
         ('catchup_apart', c_int32), ('reserved3', c_int32),
         ('loss_out', c_void_p), ('status', c_void_p),
+        ('flush_every', c_int32), ('ws_sharded', c_int32),
     ]
 
 
@@ -81,6 +82,10 @@ SIGNATURES = {
     'hsk_sample_negatives_alias': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_int64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     'hsk_bprmf_workspace_bytes': (c_int64, [c_int64] * 5),
+    'hsk_bprmf_flush_cadence': (c_int32, [POINTER(HskBprmfState), c_int32, c_int64]),
+    'hsk_shard_base_workspace_bytes': (c_int64, [c_int64] * 5),
+    'hsk_synth_degrees': (c_int, [c_int64, c_int32, c_int32, c_uint64, c_void_p, c_void_p]),
+    'hsk_synth_fill': (c_int, [c_int64, c_int64, c_int32, c_int32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'hsk_bprmf_init_workspace': (c_int, [POINTER(HskBprmfState), c_void_p]),
     'hsk_bprmf_train_step': (c_int, [POINTER(HskBprmfState), c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hsk_bprmf_train_step_sampled': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64,

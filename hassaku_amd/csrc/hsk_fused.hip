@@ -23,7 +23,7 @@
 #include <vector>
 
 #define HSK_ADAM_TAB_LEN 65536   // per-step (step_size, bc2_sqrt) table for the lazy replay
-#define HSK_FLUSH_EVERY 64       // lazy mode: dense catch-up sweep every this many steps (bounds the replay length)
+#define HSK_FLUSH_NEVER (1 << 30) // cadence of a table whose periodic sweep never pays (an explicit flush still sweeps)
 
 // =============================================================================================
 // item-partitioned forward (hsk_fwd_part.h): how many partitions for this table and batch
@@ -128,8 +128,11 @@ static inline hsk_ws hsk_select(const hsk_ws& w0, int set, int slot = 0) {
   return r;
 }
 
+// sharded: the layout of a state with ws_sharded = 1 -- the sharded step keeps the batch's user rows and gradient rows in
+// its exchange buffers (rows_all / dU_all), so the [max_batch, D] row buffers, the partial-row planes and the
+// ahead-of-time bookkeeping of the single-GPU step are not carved (several hundred MB per rank at W = 8, D = 512)
 static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
-                        int64_t max_cols) {
+                        int64_t max_cols, bool sharded = false) {
   hsk_ws w;
   char* p = (char*)base;
   int64_t off = 0;
@@ -138,7 +141,8 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
     off += hsk_align_up(bytes, 256);
     return r;
   };
-  w.n_part_max = hsk_part_rule(n_items, dim, max_batch, std::min<int64_t>(max_cols - 1, 256), false);   // an upper bound
+  w.n_part_max = sharded ? 1 : hsk_part_rule(n_items, dim, max_batch, std::min<int64_t>(max_cols - 1, 256), false);   // an upper bound
+  const int64_t row_elems = sharded ? 0 : max_batch * dim;   // one [max_batch, D] row buffer
   const int64_t ent = max_batch * (max_cols + w.n_part_max - 1);   // partitioned rows: the positive n_part times
   const int64_t hist_elems = hsk_sort_hist_elems(n_items, ent);
   const int G = hsk_group_rule(n_items, dim, max_batch, max_cols);
@@ -159,19 +163,19 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.owner = (int*)take(G * n_users * 4);
   w.cnt = (int*)take(G * n_users * 4);
   w.last_step = (int*)take(n_users * 4);
-  w.dUb = (float*)take(w.n_part_max * max_batch * dim * 4);
-  w.ucur = (float*)take(max_batch * dim * 4);
-  w.mcur = (float*)take(max_batch * dim * 4);
-  w.vcur = (float*)take(max_batch * dim * 4);
+  w.dUb = (float*)take(w.n_part_max * row_elems * 4);
+  w.ucur = (float*)take(row_elems * 4);
+  w.mcur = (float*)take(row_elems * 4);
+  w.vcur = (float*)take(row_elems * 4);
   w.loss_b = (double*)take(w.n_part_max * max_batch * 8);
   w.adam_tab = (float2*)take((HSK_ADAM_TAB_LEN + 1) * sizeof(float2));
   w.desc = (hsk_step_desc*)take(256);
   w.dupcnt = (int*)take(max_batch * 4);
   w.duplist = (int*)take(max_batch * HSK_DUP_MAX * 4);
   w.last_step_i = (int*)take(n_items * 4);
-  w.stamp = (int*)take(G * n_users * 4);
-  w.stamp_b = (int*)take(G * n_users * 4);
-  w.claim = (int*)take(n_users * 4);
+  w.stamp = (int*)take(sharded ? 0 : G * n_users * 4);
+  w.stamp_b = (int*)take(sharded ? 0 : G * n_users * 4);
+  w.claim = (int*)take(sharded ? 0 : n_users * 4);
   w.touched = (int*)take(ent * 4);
   w.touched_b = (int*)take(ent * 4);
   w.n_touched = (int*)take(256);
@@ -190,11 +194,22 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   return w;
 }
 
+static inline hsk_ws hsk_carve_st(const hsk_bprmf_state* st) {
+  return hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols, st->ws_sharded != 0);
+}
+
 extern "C" int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
                                              int64_t max_cols) {
   if (n_users <= 0 || n_items <= 0 || dim <= 0 || max_batch <= 0 || max_cols <= 1) return -1;
   if (hsk_sort_hist_elems(n_items, max_batch * (max_cols + HSK_PART_MAX - 1)) < 0) return -1;
   return hsk_carve(nullptr, n_users, n_items, dim, max_batch, max_cols).total;
+}
+
+extern "C" int64_t hsk_shard_base_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
+                                                  int64_t max_cols) {
+  if (n_users <= 0 || n_items <= 0 || dim <= 0 || max_batch <= 0 || max_cols <= 1) return -1;
+  if (hsk_sort_hist_elems(n_items, max_batch * (max_cols + HSK_PART_MAX - 1)) < 0) return -1;
+  return hsk_carve(nullptr, n_users, n_items, dim, max_batch, max_cols, true).total;
 }
 
 // lazy replay needs the per-step scalars to be constant beyond the table
@@ -217,7 +232,11 @@ static int hsk_check_state(const hsk_bprmf_state* st) {
   HSK_REQUIRE(st->max_batch > 0 && st->max_cols >= 2 && st->max_batch * st->max_cols < 0x7fffffff, HSK_ERR_INVALID,
               "bad max_batch / max_cols");
   HSK_REQUIRE(st->workspace != nullptr, HSK_ERR_INVALID, "workspace is NULL");
-  const int64_t need = hsk_bprmf_workspace_bytes(st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  HSK_REQUIRE(st->ws_sharded == 0 || st->ws_sharded == 1, HSK_ERR_INVALID, "ws_sharded must be 0 or 1");
+  HSK_REQUIRE(st->flush_every >= 0, HSK_ERR_INVALID, "flush_every must be >= 0");
+  const int64_t need = st->ws_sharded
+                           ? hsk_shard_base_workspace_bytes(st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols)
+                           : hsk_bprmf_workspace_bytes(st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
   HSK_REQUIRE(need > 0, HSK_ERR_UNSUPPORTED, "n_items %lld too large for the item sort (max %d per device)",
               (long long)st->n_items, HSK_SORT_MAX_BUCKETS * HSK_SORT_MAX_IPB);
   HSK_REQUIRE(st->workspace_bytes >= need, HSK_ERR_INVALID, "workspace too small: %lld < %lld",
@@ -249,14 +268,16 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   int rc = hsk_check_state(st);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  hsk_ws w = hsk_carve_st(st);
   const int64_t GU = (int64_t)w.group * st->n_users;   // grouped preparation: G owner maps / stamps per set
   HSK_HIP(hipMemsetAsync(w.cnt, 0, GU * 4, stream));
   HSK_HIP(hipMemsetAsync(w.cnt_b, 0, GU * 4, stream));
   HSK_HIP(hipMemsetAsync(w.dupcnt, 0, st->max_batch * 4, stream));
-  HSK_HIP(hipMemsetAsync(w.stamp, 0, GU * 4, stream));
-  HSK_HIP(hipMemsetAsync(w.stamp_b, 0, GU * 4, stream));
-  HSK_HIP(hipMemsetAsync(w.claim, 0, st->n_users * 4, stream));
+  if (!st->ws_sharded) {
+    HSK_HIP(hipMemsetAsync(w.stamp, 0, GU * 4, stream));
+    HSK_HIP(hipMemsetAsync(w.stamp_b, 0, GU * 4, stream));
+    HSK_HIP(hipMemsetAsync(w.claim, 0, st->n_users * 4, stream));
+  }
   HSK_HIP(hipMemsetAsync(w.n_touched, 0, 4, stream));
   HSK_HIP(hipMemsetAsync(w.n_touched_b, 0, 4, stream));
   k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_items, 256), 256, 0, stream>>>(w.last_step_i, st->n_items, (int)st->step);
@@ -442,9 +463,55 @@ extern "C" int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, in
 }
 
 // =============================================================================================
+// periodic sweep of the lazily updated tables: how often
+// =============================================================================================
+// A sweep brings every row of the table up to the current step: rows * D * 24 bytes of traffic (p, m, v read and
+// written), ~4.5 TB/s measured (ml10m user table: 192 us).  Without it a row replays all its pending zero-gradient
+// steps when it is next touched: VALU work, ~3.3e-13 s per element and pending step (ml10m: 4096 x 512 elements, 17
+// pending steps, 12 us).  With a fraction lambda = touched / rows of the rows touched per step and a sweep every F
+// steps, the expected pending count of a touched row is (1 - exp(-lambda F)) / lambda, hence per step
+//     cost(F) = T_sweep / F + t_replay * (1 - exp(-lambda F)) / lambda,        cost(never) = t_replay / lambda.
+// The minimum over a grid of cadences is taken; results do not depend on the cadence (any replay length is exact).
+static int hsk_flush_cadence_rule(double rows, double touched, double dim) {
+  if (rows <= 0 || touched <= 0) return HSK_FLUSH_NEVER;
+  const double t_sweep = rows * dim * 24.0 / 4.5e12;
+  const double t_replay = touched * dim * 3.3e-13;
+  const double lambda = std::min(1.0, touched / rows);
+  int best = HSK_FLUSH_NEVER;
+  double best_cost = t_replay / lambda;
+  for (double f = 16.0; f <= 8192.0; f *= 1.25) {
+    const double F = std::floor(f);
+    const double cost = t_sweep / F + t_replay * (1.0 - std::exp(-lambda * F)) / lambda;
+    if (cost < 0.97 * best_cost) {   // (a sweep has to pay for itself with some margin)
+      best_cost = cost;
+      best = (int)F;
+    }
+  }
+  return best;
+}
+
+// table 0: users, 1: items; touched: rows of that table a step touches
+static int hsk_flush_cadence(const hsk_bprmf_state* st, int table, double touched) {
+  if (table == 0 ? !st->lazy_users : !st->lazy_items) return HSK_FLUSH_NEVER;
+  static const int env = getenv("HSK_FLUSH_EVERY") ? atoi(getenv("HSK_FLUSH_EVERY")) : 0;   // experiments
+  if (st->flush_every > 0) return st->flush_every;
+  if (env > 0) return env;
+  return hsk_flush_cadence_rule((double)(table == 0 ? st->n_users : st->n_items), touched, (double)st->dim);
+}
+
+// distinct rows among `entries` uniform draws from a table of `rows` rows
+static double hsk_touched_rows(double rows, double entries) { return rows * (1.0 - std::exp(-entries / rows)); }
+
+extern "C" int32_t hsk_bprmf_flush_cadence(const hsk_bprmf_state* st, int32_t table, int64_t touched_rows) {
+  if (!st || table < 0 || table > 1 || touched_rows <= 0) return -1;
+  return hsk_flush_cadence(st, table, (double)touched_rows);
+}
+
+// =============================================================================================
 // launch sequence
 // =============================================================================================
-static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream) {
+// which: bit 0 = user table, bit 1 = item table (only the lazily updated ones are swept)
+static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream, int which = 3) {
   const int U = (int)st->n_users, D = (int)st->dim;
   if (st->step == 0) return HSK_OK;
   const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step, st->opt_kind);
@@ -453,7 +520,7 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
                                                          st->m_user_bias, st->v_user_bias, w.last_step, U, D,         \
                                                          (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN)
   const bool gen = st->opt_kind != HSK_OPT_ADAMW;
-  if (st->lazy_users) {
+  if (st->lazy_users && (which & 1)) {
     if (D % 2 == 0) {
       if (gen) HSK_FLUSH(2, true); else HSK_FLUSH(2, false);
     } else {
@@ -461,7 +528,7 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
     }
   }
 #undef HSK_FLUSH
-  if (st->lazy_items) {   // the same sweep over the item table (even dim guaranteed by hsk_check_state)
+  if (st->lazy_items && (which & 2)) {   // the same sweep over the item table (even dim guaranteed by hsk_check_state)
     const int I = (int)st->n_items;
     if (gen)
       k_user_flush<2, true><<<(unsigned)I, 256, 0, stream>>>(st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias,
@@ -474,6 +541,24 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
   }
   HSK_LAUNCH_CHECK();
   return HSK_OK;
+}
+
+// the periodic sweeps due after the steps (step_before, st->step]; user_rows / entries: what one step touches
+static int hsk_periodic_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream, int64_t step_before,
+                              double user_rows, double entries) {
+  int which = 0;
+  if (st->lazy_users) {
+    const int64_t F = hsk_flush_cadence(st, 0, user_rows);
+    if (st->step / F != step_before / F) which |= 1;
+  }
+  if (st->lazy_items) {
+    const int64_t F = hsk_flush_cadence(st, 1, hsk_touched_rows((double)st->n_items, entries));
+    if (st->step / F != step_before / F) which |= 2;
+  }
+  if (!which) return HSK_OK;
+  int rc = HSK_OK;
+  HSK_STAGE(HSK_STAGE_USER, rc = hsk_launch_flush(st, w, stream, which));
+  return rc;
 }
 
 // Item-major pass (gradient reduction [+ AdamW]).  Even D: the D-sliced, XCD-affine kernel with the widest slice the
@@ -968,15 +1053,15 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   });
   if (rc) return rc;
   HSK_LAUNCH_CHECK();
-  if (!capturing && (st->lazy_users || st->lazy_items) && (st->step % HSK_FLUSH_EVERY) == 0) {
-    int frc = 0;
-    HSK_STAGE(HSK_STAGE_USER, frc = hsk_launch_flush(st, w, stream));
+  if (!capturing && (st->lazy_users || st->lazy_items)) {
+    int frc = hsk_periodic_flush(st, w, stream, st->step - 1, (double)B, (double)(B * K_real));
     if (frc) return frc;
   }
   return HSK_OK;
 }
 
 static int hsk_check_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols) {
+  HSK_REQUIRE(!st->ws_sharded, HSK_ERR_INVALID, "state carved for the sharded step (ws_sharded = 1): use hsk_shard_*");
   HSK_REQUIRE(batch > 0 && batch <= st->max_batch, HSK_ERR_INVALID, "batch %lld outside (0, %lld]", (long long)batch,
               (long long)st->max_batch);
   HSK_REQUIRE(n_cols >= 2 && n_cols <= st->max_cols, HSK_ERR_INVALID, "n_cols %lld outside [2, %lld]",
@@ -991,7 +1076,7 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   HSK_REQUIRE(u_idx && i_idx, HSK_ERR_INVALID, "u_idx / i_idx must not be NULL");
   if ((rc = hsk_check_batch(st, batch, n_cols))) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  hsk_ws w = hsk_carve_st(st);
   const int64_t total = batch * n_cols;
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
   if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
@@ -1015,7 +1100,7 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   HSK_REQUIRE(start >= 0 && start + batch <= st->nnz, HSK_ERR_INVALID, "interaction range [%lld, %lld) outside nnz %lld",
               (long long)start, (long long)(start + batch), (long long)st->nnz);
   hipStream_t stream = (hipStream_t)stream_;
-  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  hsk_ws w = hsk_carve_st(st);
   // the RNG stream id is the index of the step about to be taken: every step draws fresh negatives
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
   hsk_aux* aux = (hsk_aux*)st->aux;
@@ -1203,7 +1288,7 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
     if ((rc = hsk_check_batch(st, batch, n_neg + 1))) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     hsk_aux* aux = (hsk_aux*)st->aux;
-    const hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+    const hsk_ws w = hsk_carve_st(st);
     const int flags = (st->lazy_users ? 1 : 0) | (st->loss_kind << 1) | (st->opt_kind << 4) | (st->lazy_items ? 64 : 0);
     while (n_steps - s >= chunk_max) {
       const int64_t n = chunk_max;
@@ -1240,9 +1325,11 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
         }
       }
       s += n;
-      // lazily updated rows: the periodic sweep that bounds the replay length closes every replayed run (the eager
-      // path sweeps at multiples of HSK_FLUSH_EVERY; the cadence is a speed matter, any replay length is exact)
-      if ((st->lazy_users || st->lazy_items) && (rc = hsk_launch_flush(st, w, stream))) return rc;
+      // lazily updated rows: the periodic sweeps that came due during the replayed run follow it (the cadence is a speed
+      // matter, any replay length is exact)
+      if ((st->lazy_users || st->lazy_items) &&
+          (rc = hsk_periodic_flush(st, w, stream, st->step - n, (double)batch, (double)(batch * (n_neg + 1)))))
+        return rc;
     }
   }
   for (; s < n_steps; ++s) {
@@ -1264,7 +1351,7 @@ extern "C" int64_t hsk_bprmf_graph_replays(const hsk_bprmf_state* st) {
 extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
   int rc = hsk_check_state(st);
   if (rc) return rc;
-  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  hsk_ws w = hsk_carve_st(st);
   // a flush ends a run of steps (epoch end, evaluation, checkpoint): a hinted or prefetched batch that was never
   // trained on must not survive it -- the next epoch's permutation may well be allocated at the same address
   if (st->aux) {
@@ -1281,7 +1368,7 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   if (rc) return rc;
   HSK_REQUIRE(u_out && i_out, HSK_ERR_INVALID, "output pointers must not be NULL");
   if ((rc = hsk_check_batch(st, batch, n_cols))) return rc;
-  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  hsk_ws w = hsk_carve_st(st);
   const int64_t total = batch * n_cols;
   if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set, ((hsk_aux*)st->aux)->cur_slot);
   // partitioned row layout: the positive sits in n_part columns, the caller sees it once
@@ -1303,7 +1390,7 @@ extern "C" int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries,
   if (rc) return rc;
   HSK_REQUIRE(perm_out && offsets_out && n_entries > 0 && n_entries <= st->max_batch * (st->max_cols + HSK_PART_MAX - 1),
               HSK_ERR_INVALID, "bad argument");
-  hsk_ws w = hsk_carve(st->workspace, st->n_users, st->n_items, st->dim, st->max_batch, st->max_cols);
+  hsk_ws w = hsk_carve_st(st);
   if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set, ((hsk_aux*)st->aux)->cur_slot);
   HSK_HIP(hipMemcpyAsync(perm_out, w.perm, n_entries * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
   HSK_HIP(hipMemcpyAsync(offsets_out, w.offsets, (st->n_items + 1) * sizeof(int), hipMemcpyDeviceToDevice,

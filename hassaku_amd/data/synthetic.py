@@ -128,3 +128,56 @@ def write_csv_dataset(data: SyntheticInteractions, path: str):
         pd.DataFrame({'user_idx': arr[:, 0], 'item_idx': arr[:, 1]}).to_csv(
             os.path.join(path, f'listening_history_{split}.csv'), index=False)
     return path
+
+
+# ------------------------------------------------------------------------------------------------
+# interactions generated on the device (BASELINE configs[4]: 100 M users x 10 M items -- no CSV, no host copy)
+# ------------------------------------------------------------------------------------------------
+DEVICE_DEG_MIN, DEVICE_DEG_SPAN, DEVICE_SKEW = 12, 17, 2      # 12..28 positives per user (mean 20), popular low ids
+
+
+class DeviceInteractions:
+    """Training interactions as the fused step takes them, generated straight into HBM by hsk_synth_* (csrc/
+    hsk_synth.hip): csr_indptr int64 [U+1], csr_indices int32 [nnz] (sorted, duplicate-free rows), coo_user int32
+    [nnz]; the COO order is the CSR order, so coo_item IS csr_indices.  A pure function of (seed, user id): every rank
+    of a job builds identical arrays without a broadcast.  Stands where TrainRecDataset._prepare_data builds the COO /
+    CSR matrices from the CSVs (data/dataset.py:120-131 of the reference)."""
+
+    def __init__(self, n_users: int, n_items: int, device, seed: int = 0, deg_min: int = DEVICE_DEG_MIN,
+                 deg_span: int = DEVICE_DEG_SPAN, skew: int = DEVICE_SKEW):
+        import ctypes  # noqa: F401
+        import torch
+        from hassaku_amd import _lib
+        _lib.require_gpu()
+        lib = _lib.load()
+        device = torch.device(device)
+        self.n_users, self.n_items, self.seed = int(n_users), int(n_items), int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.deg_min, self.deg_span, self.skew = int(deg_min), int(deg_span), int(skew)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        self.csr_indptr = torch.empty(self.n_users + 1, dtype=torch.int64, device=device)
+        _lib.check(lib.hsk_synth_degrees(self.n_users, self.deg_min, self.deg_span, self.seed,
+                                         self.csr_indptr.data_ptr(), stream), 'hsk_synth_degrees')
+        self.csr_indptr.cumsum_(0)                                       # counts -> offsets, in place
+        self.nnz = int(self.csr_indptr[-1].item())
+        self.csr_indices = torch.empty(self.nnz, dtype=torch.int32, device=device)
+        self.coo_user = torch.empty(self.nnz, dtype=torch.int32, device=device)
+        _lib.check(lib.hsk_synth_fill(self.n_users, self.n_items, self.deg_min + self.deg_span - 1, self.skew,
+                                      self.seed, self.csr_indptr.data_ptr(), self.csr_indices.data_ptr(),
+                                      self.coo_user.data_ptr(), stream), 'hsk_synth_fill')
+        self.coo_item = self.csr_indices
+
+    def __len__(self):
+        return self.nnz
+
+    def device_arrays(self, device=None):
+        """The keyword arguments BprMfFusedState / ShardedBprMf take (same keys as TrainRecDataset.device_arrays)."""
+        return dict(csr_indptr=self.csr_indptr, csr_indices=self.csr_indices, coo_user=self.coo_user,
+                    coo_item=self.coo_item)
+
+    def random_order(self, n: int, seed: int = 64):
+        """n interaction positions drawn uniformly (with replacement) -- an epoch's randperm over 2e9 interactions
+        would cost 16 GB; a run of steps only ever reads its own stretch of the order."""
+        import torch
+        gen = torch.Generator(device=self.csr_indptr.device)
+        gen.manual_seed(seed)
+        return torch.randint(0, self.nnz, (int(n),), dtype=torch.int64, device=self.csr_indptr.device, generator=gen)

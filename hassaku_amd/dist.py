@@ -131,6 +131,46 @@ class Comm:
         dist.barrier(group=self.group)
 
 
+class LoopbackComm:
+    """ONE rank of a `world`-rank job run on its own, its peers absent -- a measuring device (bench.py `cfg5_shard`:
+    rank 3 of 8 of the cfg5 job on one MI355X), not a way to train: the rank's state, shapes and kernels are exactly
+    what it has inside the real job, the collectives are local stand-ins.  all_gather: the rank's own segment is put
+    in place, the peers' segments keep what the caller put there (stand-in rows); all_reduce: the local contribution
+    alone; reduce_scatter: the rank's own segment of its own input.  RCCL time is therefore NOT in what this measures."""
+    native = True
+
+    def __init__(self, world: int, rank: int):
+        if not (0 <= rank < world):
+            raise ValueError('rank outside the world')
+        self.world, self.rank, self.group = int(world), int(rank), None
+
+    def all_reduce(self, t, async_op=False, op='sum'):
+        return _Done() if async_op else None
+
+    def all_gather_into(self, out, inp, async_op=False):
+        n = inp.shape[0]
+        out[self.rank * n:(self.rank + 1) * n].copy_(inp)
+        return _Done() if async_op else None
+
+    def reduce_scatter(self, out, inp, async_op=False):
+        n = out.shape[0]
+        out.copy_(inp[self.rank * n:(self.rank + 1) * n])
+        return _Done() if async_op else None
+
+    def all_to_all(self, out, inp, async_op=False):
+        out.copy_(inp)
+        return _Done() if async_op else None
+
+    def all_gather(self, inp):
+        return [inp.clone() for _ in range(self.world)]
+
+    def broadcast(self, t, src=0):
+        pass
+
+    def barrier(self):
+        pass
+
+
 # ------------------------------------------------------------------------------------------------
 # ownership
 # ------------------------------------------------------------------------------------------------
@@ -176,7 +216,8 @@ class ShardedBprMf:
                  batch, n_neg, csr_indptr, csr_indices, coo_user, coo_item, seed=0, beta1=ADAM_BETA1,
                  beta2=ADAM_BETA2, eps=None, capacity: Optional[int] = None, entry_cap: Optional[int] = None,
                  loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto', prefetch=True,
-                 inputs_are_shards=False, n_users: Optional[int] = None, n_items: Optional[int] = None):
+                 inputs_are_shards=False, n_users: Optional[int] = None, n_items: Optional[int] = None,
+                 flush_every: int = 0, item_shard=None):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.comm = comm
@@ -192,6 +233,15 @@ class ShardedBprMf:
         else:
             U, I = user_emb.shape[0], item_emb.shape[0]
         lo, hi = item_range(I, r, W)
+        if item_shard is not None:
+            # this rank's item range given explicitly (inputs_are_shards only): one rank's share of a LARGER job run on
+            # its own -- e.g. the range rank 3 of 8 owns of the cfg5 catalogue, with a 1-rank group: it samples over all
+            # n_items and keeps what falls into [lo, hi), exactly as that rank would (tests, bench.py cfg5_shard)
+            if not inputs_are_shards:
+                raise ValueError('item_shard needs inputs_are_shards=True')
+            lo, hi = int(item_shard[0]), int(item_shard[1])
+            if not (0 <= lo < hi <= I):
+                raise ValueError(f'item_shard {item_shard} outside [0, {I})')
         if hi <= lo:
             raise ValueError(f'rank {r} of {W} would own no items (n_items = {I})')
         self.device, self.n_users_global, self.n_items, self.dim = dev, U, I, D
@@ -228,8 +278,11 @@ class ShardedBprMf:
         # capacities from the data: the share of the interactions the busiest owner holds, and the probability
         # that a drawn negative falls into this rank's item range (interaction-weighted over the users)
         if capacity is None:
-            share = torch.bincount(coo_user.long() % W, minlength=W).double().max().item() / max(nnz, 1)
-            capacity = user_capacity(max(share, 1.0 / W), G)
+            if nnz > (1 << 28):   # (a count over billions of interactions: the shares are 1/W to four digits)
+                share = 1.02 / W
+            else:
+                share = torch.bincount(coo_user.long() % W, minlength=W).double().max().item() / max(nnz, 1)
+            capacity = user_capacity(min(1.0, max(share, 1.0 / W)), G)
         if entry_cap is None:
             deg = (csr_indptr[1:] - csr_indptr[:-1]).double()
             inv_free = float((deg / (I - deg).clamp(min=1.0)).sum().item()) / max(float(deg.sum().item()), 1.0)
@@ -252,7 +305,8 @@ class ShardedBprMf:
         self.loss_out = torch.zeros(2, dtype=torch.float64, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         max_batch, max_cols = max(G, C), K
-        nbytes = self.lib.hsk_bprmf_workspace_bytes(U_loc, I_loc, D, max_batch, max_cols)
+        # (the sharded carving: no [max_batch, D] row buffers -- the step works through rows_all / dU_all)
+        nbytes = self.lib.hsk_shard_base_workspace_bytes(U_loc, I_loc, D, max_batch, max_cols)
         sbytes = self.lib.hsk_shard_workspace_bytes(max_batch, max_cols, C, cap)
         if nbytes <= 0 or sbytes <= 0:
             raise ValueError('invalid workspace request')
@@ -281,6 +335,7 @@ class ShardedBprMf:
         st.workspace, st.workspace_bytes = _p(self.workspace), nbytes
         st.max_batch, st.max_cols = max_batch, max_cols
         st.lazy_users = 1
+        st.ws_sharded, st.flush_every = 1, int(flush_every)
         st.graph_chunk, st.catchup_apart = -1, 0
         if lazy_items == 'auto':   # worth it when most of the shard's rows are outside every batch
             lazy_items = D % 2 == 0 and I_loc >= 2 * cap and I_loc * D > hip_ops.LAZY_USERS_MIN_ELEMENTS
@@ -309,6 +364,13 @@ class ShardedBprMf:
     @property
     def step_count(self) -> int:
         return int(self.sh.base.step)
+
+    def flush_cadence(self):
+        """(steps between sweeps of the local user shard, of the local item shard); 2**30 = never (explicit flush only)"""
+        st = ctypes.byref(self.sh.base)
+        touched_items = self.item_emb.shape[0] * (1.0 - math.exp(-self.entry_cap / self.item_emb.shape[0]))
+        return (int(self.lib.hsk_bprmf_flush_cadence(st, 0, self.capacity)),
+                int(self.lib.hsk_bprmf_flush_cadence(st, 1, max(1, int(touched_items)))))
 
     # -- one global step -------------------------------------------------------------------------------------
     def _prepare(self, order, start_global, nb, set_, stream):
@@ -370,17 +432,31 @@ class ShardedBprMf:
         _lib.check(self.lib.hsk_shard_discard(ctypes.byref(self.sh), self._pf[4], _stream()), 'hsk_shard_discard')
         self._pf = None
 
-    def last_batch(self, batch: Optional[int] = None):
-        """(offs int32 [G+1], local item ids int32 [entry_cap] (-1 beyond the kept entries), users int32 [G]) of the
-        batch of the latest step -- debug / parity."""
+    def peek_batch(self, order: Optional[torch.Tensor], start_global: int, batch: Optional[int] = None):
+        """The batch the NEXT step_sampled(order, start_global, batch) will train on, as this rank keeps it (same
+        triple as last_batch()) -- debug / parity: it is prepared into the idle buffer set, read and discarded; the
+        step then prepares it again (same RNG stream id: identical samples)."""
         nb = self.batch if batch is None else int(batch)
+        self._discard_prefetch()
+        set_ = self._cur_set ^ 1
+        self._prepare(order, int(start_global), nb, set_, _stream())
+        out = self._read_batch(set_, nb)
+        _lib.check(self.lib.hsk_shard_discard(ctypes.byref(self.sh), set_, _stream()), 'hsk_shard_discard')
+        return out
+
+    def _read_batch(self, set_, nb):
         G = self.comm.world * nb
         offs = torch.empty(G + 1, dtype=torch.int32, device=self.device)
         items = torch.empty(self.entry_cap, dtype=torch.int32, device=self.device)
         u = torch.empty(G, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.hsk_shard_last_batch(ctypes.byref(self.sh), self._cur_set, nb, _p(offs), _p(items), _p(u),
+        _lib.check(self.lib.hsk_shard_last_batch(ctypes.byref(self.sh), set_, nb, _p(offs), _p(items), _p(u),
                                                  _stream()), 'hsk_shard_last_batch')
         return offs, items, u
+
+    def last_batch(self, batch: Optional[int] = None):
+        """(offs int32 [G+1], local item ids int32 [entry_cap] (-1 beyond the kept entries), users int32 [G]) of the
+        batch of the latest step -- debug / parity."""
+        return self._read_batch(self._cur_set, self.batch if batch is None else int(batch))
 
     # -- per-stage device timing (same recorder as the single-GPU state; 'fwd', 'item', 'user' are bracketed) ------
     def enable_timing(self, stages=('fwd',), every=1):
@@ -515,6 +591,9 @@ def evaluate_item_sharded(comm: Comm, sharded, dataset, evaluator, chunk: Option
     if I < k:
         raise ValueError(f'full evaluation needs at least {k} items (K_VALUES), got {I}')
     kk = min(k, I_loc)
+    if W * k > 4096:
+        raise ValueError(f'item-sharded evaluation merges world x k = {W} x {k} candidates per user; hsk_topk_merge takes '
+                         f'at most 4096 (use fewer ranks per evaluation group or a smaller K)')
     n_groups = evaluator.get_n_groups()
     groups = evaluator.get_user_to_user_group().to(dev) if n_groups > 0 else None
     sums = torch.zeros((n_groups + 1, len(ks), 3), dtype=torch.float64, device=dev)
@@ -590,6 +669,31 @@ def evaluate_item_sharded(comm: Comm, sharded, dataset, evaluator, chunk: Option
     comm.all_reduce(sums)
     comm.all_reduce(counts)
     return _metric_dict(sums.cpu(), counts.cpu(), ks, n_groups)
+
+
+def init_shard_tables(rank: int, world: int, n_users: int, n_items: int, dim: int, device, seed: int = 64,
+                      item_bias: bool = True, user_bias: bool = False, rows_per_call: int = 1 << 20):
+    """This rank's shards of freshly initialised tables, created directly on the device: user rows rank::world, item
+    rows item_range(...).  The law is the reference's (general_weight_init, train/utils.py:5-13: N(0, (0.1/D)^2) for the
+    embeddings, N(0, 0.1^2) for the [., 1] bias tables); the STREAM is per shard (seed, rank) -- tables this large never
+    exist in one piece, so there is no single-device initialisation to be bit-identical to (smaller jobs keep the
+    seeded full-table init and cut it: ShardedBprMf without inputs_are_shards).  -> dict of tensors."""
+    device = torch.device(device)
+    U_loc = local_user_count(n_users, rank, world)
+    lo, hi = item_range(n_items, rank, world)
+    gen = torch.Generator(device=device)
+    gen.manual_seed((int(seed) * 1000003 + rank) & 0x7fffffffffffffff)
+
+    def table(rows, cols, std):
+        t = torch.empty((rows, cols), dtype=torch.float32, device=device)
+        for r0 in range(0, rows, rows_per_call):       # bounded calls: a 51 GB table is 12.8e9 elements
+            t[r0:r0 + rows_per_call].normal_(mean=0.0, std=std, generator=gen)
+        return t
+
+    out = {'user_emb': table(U_loc, dim, 0.1 / dim), 'item_emb': table(hi - lo, dim, 0.1 / dim),
+           'item_bias': table(hi - lo, 1, 0.1).view(-1) if item_bias else None,
+           'user_bias': table(U_loc, 1, 0.1).view(-1) if user_bias else None}
+    return out
 
 
 def _metric_dict(sums, counts, ks, n_groups):

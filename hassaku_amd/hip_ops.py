@@ -328,7 +328,8 @@ class BprMfFusedState:
     def __init__(self, user_emb, item_emb, item_bias=None, user_bias=None, global_bias=None, *, lr, wd,
                  max_batch, max_cols, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=None, seed=0,
                  csr_indptr=None, csr_indices=None, coo_user=None, coo_item=None, lazy_users='auto', overlap=True,
-                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto', graph_chunk=0):
+                 loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto', graph_chunk=0,
+                 flush_every=0):
         _lib.require_gpu()
         if optimizer not in OPT_KINDS:
             raise ValueError(f'Optimizer {optimizer} not yet implemented')
@@ -393,6 +394,9 @@ class BprMfFusedState:
         # steps_sampled() replays its steady-state loop as HIP graphs of this many steps (0: default 64, < 0: never)
         st.graph_chunk = int(graph_chunk)
         st.catchup_apart = 0
+        # steps between the periodic sweeps of the lazily updated tables; 0: from the table / batch sizes
+        # (hsk_bprmf_flush_cadence; a speed matter only -- every cadence gives the same bits)
+        st.flush_every, st.ws_sharded = int(flush_every), 0
         st.timing_mask = 0
         if loss not in LOSS_KINDS:
             raise ValueError(f'unknown loss {loss!r}')
@@ -449,6 +453,16 @@ class BprMfFusedState:
                 raise ValueError('order too short')
         _lib.check(self.lib.hsk_bprmf_train_steps(ctypes.byref(self.st), _p(order), start, n_steps, batch, n_neg,
                                                   _stream()), 'hsk_bprmf_train_steps')
+
+    def flush_cadence(self, batch: Optional[int] = None):
+        """(steps between sweeps of the user table, of the item table) for batches of `batch` positives;
+        2**30 = never (only flush() sweeps)."""
+        import math
+        b = self.max_batch if batch is None else int(batch)
+        n_items = self.params['item_emb'].shape[0]
+        touched = max(1, int(n_items * (1.0 - math.exp(-b * self.max_cols / n_items))))
+        ref = ctypes.byref(self.st)
+        return int(self.lib.hsk_bprmf_flush_cadence(ref, 0, b)), int(self.lib.hsk_bprmf_flush_cadence(ref, 1, touched))
 
     def graph_replays(self) -> int:
         """Runs of steps_sampled() issued as replayed HIP graphs so far."""

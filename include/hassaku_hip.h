@@ -237,10 +237,25 @@ typedef struct hsk_bprmf_state {
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;
+  /* lazy AdamW: every flush_every-th step sweeps the lazily updated tables (every row brought up to the current step),
+     which bounds how many zero-gradient steps a row replays when it is next touched.  A speed matter only -- any
+     cadence is exact.  0: chosen from the table and batch sizes (hsk_bprmf_flush_cadence) */
+  int32_t flush_every;
+  /* 1: workspace carved for the sharded step (hsk_shard_*), which keeps the batch's user rows and their gradients in
+     its exchange buffers: the [max_batch, dim] row buffers of the single-GPU step are not allocated.  The size is then
+     hsk_shard_base_workspace_bytes(); the single-GPU entry points refuse such a state */
+  int32_t ws_sharded;
 } hsk_bprmf_state;
 
 int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim,
                                   int64_t max_batch, int64_t max_cols);
+/* Steps between two sweeps of a lazily updated table (table 0: users, 1: items) of which a step touches about
+ * `touched_rows` rows, as the step picks it when st->flush_every == 0.  A sweep moves 24 bytes per table element; a
+ * touched row replays its pending zero-gradient steps (VALU work, ~3.3e-13 s per element and step).  The cadence that
+ * minimises the sum: ~sqrt(rows / touched_rows) * 5 while a row waits much longer than that for its next batch (a
+ * cfg5 shard: ~210), never (2^30: only an explicit flush sweeps) when a row is touched every few steps anyway
+ * (ml10m: a user is in every 17th batch). */
+int32_t hsk_bprmf_flush_cadence(const hsk_bprmf_state* st, int32_t table, int64_t touched_rows);
 int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t stream);
 
 /* One step on a loader-provided batch (u_idx [batch], i_idx [batch, n_cols], column 0 positive):
@@ -392,6 +407,9 @@ typedef struct hsk_bprmf_shard {
 } hsk_bprmf_shard;
 
 int64_t hsk_shard_workspace_bytes(int64_t max_batch, int64_t max_cols, int64_t capacity, int64_t entry_cap);
+/* size of base.workspace with base.ws_sharded = 1 (no [max_batch, dim] row buffers) */
+int64_t hsk_shard_base_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim, int64_t max_batch,
+                                       int64_t max_cols);
 int hsk_shard_init(hsk_bprmf_shard* sh, hsk_stream_t stream);   /* after hsk_bprmf_init_workspace(&sh->base) */
 int hsk_shard_prepare(hsk_bprmf_shard* sh, const int64_t* order, int64_t start_global, int64_t batch, int64_t n_neg,
                       int32_t set, hsk_stream_t stream);
@@ -409,6 +427,23 @@ int hsk_shard_flush(hsk_bprmf_shard* sh, hsk_stream_t stream);
  * offs [world*batch + 1], local item ids items [entry_cap], user ids u [world*batch] (device int32 arrays) */
 int hsk_shard_last_batch(const hsk_bprmf_shard* sh, int32_t set, int64_t batch, int32_t* offs_out, int32_t* items_out,
                          int32_t* u_out, hsk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic training interactions generated straight into HBM (BASELINE configs[4]: 100 M users x 10 M items; no CSV
+ * is ever written).  Stands where TrainRecDataset._prepare_data builds the COO iteration matrix and the CSR sampling
+ * matrix from listening_history_train.csv (data/dataset.py:120-131): same arrays, same invariants (CSR rows sorted and
+ * duplicate-free; the COO lists every interaction once).  The COO order is the CSR order: coo_item == csr_indices.
+ * A pure function of (seed, user id) -- every rank generates identical arrays; law in csrc/hsk_synth.hip.
+ *   hsk_synth_degrees   indptr[0] = 0, indptr[u+1] = deg(u) in [deg_min, deg_min + deg_span); the caller turns the
+ *                       counts into offsets by an inclusive scan of indptr[1..] (in place)
+ *   hsk_synth_fill      csr_indices[indptr[u] .. indptr[u+1]) = the user's items, coo_user likewise = u (may be NULL);
+ *                       deg_max = deg_min + deg_span - 1 <= min(64, n_items); skew = 1 (uniform items), 2, 3 (popular
+ *                       low ids: item = floor(I * x^skew), x stratified-uniform)
+ * ------------------------------------------------------------------------------------------ */
+int hsk_synth_degrees(int64_t n_users, int32_t deg_min, int32_t deg_span, uint64_t seed, int64_t* indptr,
+                      hsk_stream_t stream);
+int hsk_synth_fill(int64_t n_users, int64_t n_items, int32_t deg_max, int32_t skew, uint64_t seed,
+                   const int64_t* indptr, int32_t* csr_indices, int32_t* coo_user, hsk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Full-catalogue evaluation (eval/eval.py:237-253, eval/eval.py:54-99, eval/metrics.py:4-105)

@@ -299,3 +299,60 @@ def full_eval_metrics(U, I, Ib, Ub, gb, u_all, excl_indptr, excl_indices, lab_in
     for (g, name), s in sums.items():
         out[name if g == -1 else f'group_{g}_{name}'] = s / counts[g]
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic interactions generated on the device (hassaku_amd/csrc/hsk_synth.hip): numpy restatement of the law
+# (no reference counterpart: the reference reads processed CSVs, data/dataset.py:120-131; this pins the generator
+# the cfg5 workload trains on, so that a test can rebuild any user's row on the host)
+# ------------------------------------------------------------------------------------------------
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 on uint32 numpy arrays (the same rounds as hsk_philox4x32_10 in csrc/hsk_common.h)."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint32) for x in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0.astype(np.uint64)
+        p1 = M1 * c2.astype(np.uint64)
+        n0 = (p1 >> np.uint64(32)).astype(np.uint32) ^ c1 ^ np.uint32(k0)
+        n1 = p1.astype(np.uint32)
+        n2 = (p0 >> np.uint64(32)).astype(np.uint32) ^ c3 ^ np.uint32(k1)
+        n3 = p0.astype(np.uint32)
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def synth_degrees(users, deg_min, deg_span, seed):
+    """deg(u) of hsk_synth_degrees for an array of user ids."""
+    u = np.asarray(users, dtype=np.uint64)
+    z = np.zeros(len(u), dtype=np.uint32)
+    r = _philox4x32_10((u & np.uint64(0xFFFFFFFF)).astype(np.uint32), (u >> np.uint64(32)).astype(np.uint32), z,
+                       z + np.uint32(0xD), seed & 0xFFFFFFFF, seed >> 32)[0]
+    return deg_min + (r % np.uint32(deg_span)).astype(np.int64)
+
+
+def synth_rows(users, n_items, deg_min, deg_span, skew, seed):
+    """The item rows hsk_synth_fill writes for `users` -> list of int32 arrays (sorted, duplicate-free)."""
+    users = np.asarray(users, dtype=np.int64)
+    degs = synth_degrees(users, deg_min, deg_span, seed)
+    out = []
+    for u, deg in zip(users, degs):
+        j = np.arange(deg)
+        uu = np.full(deg, u, dtype=np.uint64)
+        r = _philox4x32_10((uu & np.uint64(0xFFFFFFFF)).astype(np.uint32), (uu >> np.uint64(32)).astype(np.uint32),
+                           (j >> 2).astype(np.uint32), np.full(deg, 0xE, dtype=np.uint32), seed & 0xFFFFFFFF, seed >> 32)
+        w = np.choose(j & 3, r).astype(np.float64)
+        x = (j.astype(np.float64) + (w + 0.5) * (1.0 / 4294967296.0)) / np.float64(deg)
+        t = x.copy()
+        for _ in range(1, skew):
+            t = t * x
+        v = np.minimum((t * np.float64(n_items)).astype(np.int64), n_items - 1)
+        for q in range(1, deg):
+            if v[q] <= v[q - 1]:
+                v[q] = v[q - 1] + 1
+        for q in range(deg - 1, -1, -1):
+            cap = n_items - 1 if q == deg - 1 else v[q + 1] - 1
+            v[q] = min(v[q], cap)
+        out.append(v.astype(np.int32))
+    return out

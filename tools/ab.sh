@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B helper: run bench.py with every stage timed under different env settings and print one line each.
-# usage: [ABFLAGS="--workload ml1m --no-prefetch"] tools_ab.sh "NAME=VAL ..." "NAME=VAL ..." ...   ("" = defaults)
+# usage: [ABFLAGS="--workload ml1m --no-prefetch"] tools/ab.sh "NAME=VAL ..." "NAME=VAL ..." ...   ("" = defaults)
 for cfg in "$@"; do
   out=$(env $cfg timeout -k 10 300 python bench.py --steps 128 --warmup 10 --cpu-budget 0 --time-all-stages $ABFLAGS 2>&1 | tail -1)
   echo "$out" | python3 -c "

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two builds on one box (HSK_LIB_PATH): put the other build at hassaku_amd/libhsk_old_ab.so.
-# usage: tools_ab_lib.sh <workload> <steps> <warmup> : alternates HSK_LIB_PATH old/new three times
+# usage: tools/ab_lib.sh <workload> <steps> <warmup> : alternates HSK_LIB_PATH old/new three times
 W=$1; S=$2; U=$3
 for i in 1 2 3; do
   for lib in libhsk_old_ab.so libhassaku_hip.so; do

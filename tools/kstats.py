@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print the per-kernel summary of a rocprofv3 --kernel-trace --stats run.  usage: tools_kstats.py <dir> [n]"""
+"""Print the per-kernel summary of a rocprofv3 --kernel-trace --stats run.  usage: tools/kstats.py <dir> [n]"""
 import csv
 import glob
 import sys

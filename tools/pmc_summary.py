@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of tools_profile.sh into profiles/<name>/{kernel_stats.csv, pmc_summary.json}.
-usage: tools_pmc_summary.py gpurun_out/prof_<tag> profiles/<name>
+"""Condense the rocprofv3 outputs of tools/profile.sh into profiles/<name>/{kernel_stats.csv, pmc_summary.json}.
+usage: tools/pmc_summary.py gpurun_out/prof_<tag> profiles/<name>
 Only this repo's kernels (k_*) are kept; counter values are the per-dispatch means, in the units rocprofv3 reports."""
 import csv
 import glob

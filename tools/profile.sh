@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun): kernel trace + stats, then one PMC pass per counter.
-# usage: bash tools_profile.sh <tag> [bench args...]
+# usage: bash tools/profile.sh <tag> [bench args...]
 set -o pipefail
 TAG=${1:-r1}; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Print the kernel timeline of the last few steps of a rocprofv3 --kernel-trace run.
-usage: tools_timeline.py <dir> [anchor kernel prefix] [n_steps]"""
+usage: tools/timeline.py <dir> [anchor kernel prefix] [n_steps]"""
 import csv
 import glob
 import sys
