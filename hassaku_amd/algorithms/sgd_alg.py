@@ -8,6 +8,7 @@ containers only: every score is computed by hsk_mf_scores / the eval GEMM of lib
 There is no CPU forward -- calling the model on CPU tensors raises.
 """
 import logging
+import weakref
 from typing import NamedTuple, Optional
 
 import torch
@@ -181,13 +182,16 @@ class SGDMatrixFactorization(SGDBasedRecommenderAlgorithm):
     def _score_all(self, u_idxs: torch.Tensor, i_idxs: torch.Tensor) -> torch.Tensor:
         n = i_idxs.numel()
         # whole catalogue in catalogue order?  Decided by comparing with arange (any permutation takes the general
-        # path); the verdict is remembered per index tensor, so an evaluation loop syncs once, not once per batch
-        key = (i_idxs.data_ptr(), n, i_idxs._version)
-        if getattr(self, '_full_key', None) != key:
-            self._full_key = key
-            self._full_val = n == self.n_items and bool(
+        # path).  The verdict is remembered for THE TENSOR OBJECT it was reached on (held by a weak reference and
+        # compared with `is`, plus its in-place version counter), so an evaluation loop that passes the same index
+        # tensor every batch syncs once -- never keyed on the address: the caching allocator hands a freed block to
+        # the next tensor of the same size.
+        cached = getattr(self, '_full_ref', None)
+        if cached is None or cached[0]() is not i_idxs or cached[1] != i_idxs._version:
+            full = n == self.n_items and bool(
                 torch.equal(i_idxs, torch.arange(n, dtype=i_idxs.dtype, device=i_idxs.device)))
-        full = self._full_val
+            self._full_ref = (weakref.ref(i_idxs), i_idxs._version, full)
+        full = self._full_ref[2]
         user_emb, item_emb, ib, ub, gb = self.tables()
         if full:
             _, _, scores = hip_ops.mf_eval_topk(user_emb, item_emb, ib, ub, gb, u_idxs.contiguous(), 0,

@@ -402,6 +402,7 @@ struct hsk_aux {
     hipGraphExec_t exec;
     int64_t n_steps, batch, n_neg;
     int set0, flags;
+    hsk_bprmf_state key;   // the state as captured (hsk_graph_key): a replay is only valid for exactly this state
   };
   std::vector<graph_entry> graphs;
   bool graph_broken = false;   // a capture failed once: stay with eager launches
@@ -1139,6 +1140,21 @@ __global__ void k_set_desc(hsk_step_desc* d, long long start0, const int64_t* or
 #define HSK_GRAPH_DEFAULT_CHUNK 64
 #define HSK_GRAPH_MAX_CACHED 8
 
+// What a captured graph has frozen into its kernel arguments: every pointer of the state (tables, moments, biases,
+// CSR / COO, alias table, workspace, loss_out, status), the shapes, the hyper-parameters (lr, wd, betas, eps -> the
+// optimiser scalars and the Adam table), seed, loss / optimiser kind, the lazy flags.  Only the step counter and the
+// timing fields may differ between capture and replay (the former is read from the device descriptor).  A caller that
+// changes anything else between two hsk_bprmf_train_steps calls -- an LR schedule through st->lr, parameters rebound
+// after .to(), a new dataset -- gets a fresh capture, exactly as the eager path would pick the new values up.
+static hsk_bprmf_state hsk_graph_key(const hsk_bprmf_state* st) {
+  hsk_bprmf_state k;
+  memcpy(&k, st, sizeof(k));
+  k.step = 0;
+  k.timing = nullptr;
+  k.timing_mask = k.timing_every = k.timing_now = 0;
+  return k;
+}
+
 static int64_t hsk_graph_chunk(const hsk_bprmf_state* st) {
   static const int env = getenv("HSK_GRAPH") ? atoi(getenv("HSK_GRAPH")) : 1;
   if (!env || st->graph_chunk < 0) return 0;
@@ -1296,8 +1312,20 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
       aux->hint_valid = false;
       const int set0 = 0;   // the buffer sets are scratch: with no prepared batch pending a run may start with either
       hipGraphExec_t exec = nullptr;
-      for (auto& g : aux->graphs)
-        if (g.n_steps == n && g.batch == batch && g.n_neg == n_neg && g.set0 == set0 && g.flags == flags) exec = g.exec;
+      const hsk_bprmf_state key = hsk_graph_key(st);
+      for (size_t gi = 0; gi < aux->graphs.size();) {
+        auto& g = aux->graphs[gi];
+        if (g.n_steps == n && g.batch == batch && g.n_neg == n_neg && g.set0 == set0 && g.flags == flags) {
+          if (memcmp(&g.key, &key, sizeof(key)) == 0) {
+            exec = g.exec;
+          } else {   // same shape, another state: the captured arguments are stale
+            (void)hipGraphExecDestroy(g.exec);
+            aux->graphs.erase(aux->graphs.begin() + gi);
+            continue;
+          }
+        }
+        ++gi;
+      }
       if (!exec) {
         if ((rc = hsk_capture_steps(st, w, n, batch, n_neg, set0, &exec))) {
           aux->graph_broken = true;   // eager launches from here on (the error text stays available)
@@ -1307,7 +1335,7 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
           (void)hipGraphExecDestroy(aux->graphs.front().exec);
           aux->graphs.erase(aux->graphs.begin());
         }
-        aux->graphs.push_back({exec, n, batch, n_neg, set0, flags});
+        aux->graphs.push_back({exec, n, batch, n_neg, set0, flags, key});
       }
       k_set_desc<<<1, 1, 0, stream>>>(w.desc, (long long)(start + s * batch), order, (int)st->step);
       HSK_LAUNCH_CHECK();

@@ -110,8 +110,19 @@ class Trainer:
         user_emb, item_emb, ib, ub, gb = self.model.tables()
         loader = self.train_loader
         arrays = loader.dataset.device_arrays(torch.device(self.device))
+        # Batch semantics at N > 1.  conf['multi_gpu_batch']:
+        #   'per_rank' (default)  every rank contributes train_batch_size positives, a step trains on world x
+        #                         train_batch_size of them (weak scaling; lr unchanged -- NOT what the same conf does
+        #                         on one GPU);
+        #   'global'              a step trains on train_batch_size positives, train_batch_size / world per rank --
+        #                         what nn.DataParallel does with the configured batch (train/trainer.py:38-41 of the
+        #                         reference): the same optimisation as on one GPU.
+        mode = conf.get('multi_gpu_batch', 'per_rank')
+        if mode not in ('per_rank', 'global'):
+            raise ValueError(f"multi_gpu_batch must be 'per_rank' or 'global', got {mode!r}")
+        self._rank_batch = loader.batch_size if mode == 'per_rank' else max(1, loader.batch_size // self.comm.world)
         sh = ShardedBprMf(self.comm, user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd,
-                          batch=loader.batch_size, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed,
+                          batch=self._rank_batch, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed,
                           loss=self.rec_loss.kind, log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0),
                           alias=loader.interaction_sampler.alias(torch.device(self.device)),
                           optimizer=conf['optimizer'], **arrays)
@@ -160,7 +171,7 @@ class Trainer:
         if order is not None:
             self.comm.broadcast(order, src=0)   # one epoch order for the whole job
         loader.epoch += 1
-        n, bs = len(loader.dataset), loader.batch_size
+        n, bs = len(loader.dataset), self._rank_batch
         steps, pos = 0, 0
         while n - pos >= W:
             nb = min(bs, (n - pos) // W)
@@ -169,8 +180,9 @@ class Trainer:
             sh.step_sampled(order, pos, nb, next_start=nxt if nnb > 0 else None, next_batch=nnb)
             pos = nxt
             steps += 1
-            if steps == 1:
-                sh.check_status()                   # a capacity that is too small shows on the first batch
+            if steps == 1 or steps % 256 == 0:
+                sh.check_status()                   # a capacity that is too small shows on the first batch; later
+                                                    # overflows (the step is then invalid) within 256 steps
         sh.flush()
         rec = sh.pop_loss_sum() / max(steps, 1)
         sh.check_status()

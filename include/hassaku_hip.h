@@ -310,7 +310,11 @@ int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, int64_t start
  * issued from C.  At small batches the step is bound by the host's launch rate (ten HIP calls of 3-4 us each plus the
  * interpreter), not by the GPU: with st->aux set (and an even dim, no lazy_items, no stage timing) runs of consecutive
  * steps are captured once as a HIP graph and REPLAYED (st->graph_chunk steps per graph), the per-step scalars coming
- * from a device-resident descriptor; same kernels, same order, bit-identical results. */
+ * from a device-resident descriptor; same kernels, same order, bit-identical results.
+ * A captured graph has the state frozen into its kernel arguments (every pointer, the shapes, lr / wd / betas / eps,
+ * seed, loss and optimiser kind, the lazy flags); it is replayed only while the state is byte-for-byte what it was at
+ * capture time, `step` and the timing fields aside -- change anything else between two calls (an LR schedule through
+ * st->lr, rebound parameters, another dataset) and the run is captured afresh, as the eager path would see it. */
 int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t n_steps, int64_t batch,
                           int64_t n_neg, hsk_stream_t stream);
 

@@ -356,7 +356,7 @@ def test_sampler_same_law_as_reference_style_sampler(ops, oracle):
         cb = np.bincount(b[r], minlength=n_items).astype(np.float64)
         assert np.array_equal(ca > 0, cb > 0) or (ca + cb)[(ca > 0) != (cb > 0)].max() < 5
         sel = (ca + cb) > 0
-        chi2 = (((ca - cb) ** 2) / (ca + cb))[sel].sum()
+        chi2 = ((ca[sel] - cb[sel]) ** 2 / (ca[sel] + cb[sel])).sum()
         assert chi2 < 2.5 * sel.sum(), (r, chi2, sel.sum())
 
 
@@ -986,3 +986,54 @@ def test_eval_cfg4_shape_eight_item_shards_vs_float64(ops):
     clear = gap & torch.cat([torch.ones_like(gap[:, :1]), gap[:, :-1]], dim=1)
     assert clear.float().mean() > 0.9
     assert torch.equal(mi.long()[clear], ri[:, :k][clear])
+
+
+def test_replayed_graph_is_recaptured_when_the_state_changes(ops):
+    """A captured run has lr / wd / pointers frozen into its kernel arguments: changing st.lr between two
+    steps_sampled() calls (an LR schedule) must give what the eager path gives, bit for bit -- i.e. a fresh capture,
+    never a replay of the stale graph."""
+    n_users, n_items, D, B, N = 300, 900, 64, 128, 6
+    rng = np.random.RandomState(4)
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.15)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
+    order = torch.from_numpy(np.concatenate([np.random.RandomState(r).permutation(len(pairs)) for r in range(2)])).cuda()
+    res = []
+    for chunked in (False, True):
+        st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                             coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+        st.st.nnz = order.numel()
+        for run, lr in enumerate((1e-3, 5e-2, 1e-3)):          # back to the first value: that graph may be cached
+            st.st.lr = lr
+            if chunked:
+                st.steps_sampled(order, run * 64 * B, 64, B, N)
+            else:
+                for s in range(64):
+                    st.step_sampled(order, (run * 64 + s) * B, B, N)
+        st.flush()
+        st.check_status()
+        assert st.graph_replays() == (3 if chunked else 0)
+        res.append({k: v.cpu().numpy().copy() for k, v in t.items()})
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_score_all_fast_path_is_not_keyed_on_the_address():
+    """_score_all remembers 'i_idxs is arange(n_items)' per tensor OBJECT: a permutation that the caching allocator
+    places at the freed arange's address must take the general path (scores in the order of the given ids)."""
+    from hassaku_amd.algorithms.sgd_alg import SGDMatrixFactorization
+    torch.manual_seed(3)
+    m = SGDMatrixFactorization(50, 4096, 32, False, True, False).to('cuda')
+    u = torch.arange(8, device='cuda')
+    ar = torch.arange(4096, device='cuda')
+    full = m.combine_user_item_representations(m.get_user_representations(u), m.get_item_representations(ar))
+    addr = ar.data_ptr()
+    del ar
+    perm = torch.randperm(4096, device='cuda')
+    same_block = perm.data_ptr() == addr          # what the caching allocator usually does
+    out = m.combine_user_item_representations(m.get_user_representations(u), m.get_item_representations(perm))
+    assert torch.allclose(out, full[:, perm], rtol=1e-5, atol=1e-7), same_block
+    assert not torch.equal(out, full)
