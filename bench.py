@@ -145,11 +145,14 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     def run(n, first):
         if comm is None:
             # the epoch's inner loop, issued from C in runs of consecutive batches (hsk_bprmf_train_steps: each step
-            # hints the next one to the prefetch); a run ends where the epoch order wraps around
+            # hints the next one to the prefetch); a run ends where the epoch order wraps around, and its last step is
+            # told the batch that follows the run -- the loader always knows it -- so every step of the timed region,
+            # the first and the last included, is the steady-state step
             s = 0
             while s < n:
                 k0 = (first + s) % n_batches
                 m = min(n - s, n_batches - k0, 256)
+                st.hint_after_run(order, ((k0 + m) % n_batches) * B, B, N)
                 st.steps_sampled(order, k0 * B, m, B, N)
                 s += m
             return
@@ -163,7 +166,18 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
             comm.barrier()
         torch.cuda.synchronize()
 
-    run(warmup, 0)
+    # (a short --warmup leaves the clocks, the caches and the prefetch pipeline cold: at least 32 untimed steps are run)
+    warmup_run = max(warmup, 32) if comm is None else warmup
+    if comm is None:
+        # ... and the lazily updated tables are swept two steps before the fence (a flush right at the fence would drop
+        # the batch the last warm-up step prepared): the timed region starts with (almost) every row current and ends
+        # with every row current -- it pays for its own steps' dense-AdamW work, not for the warm-up's backlog
+        run(warmup_run - 2, 0)
+        st.flush()
+        run(2, warmup_run - 2)
+    else:
+        run(warmup_run, 0)
+    warmup = warmup_run
     fence()
     st.check_status('warm-up')
     # Small batches (the reference's usual 128..512) run as replayed HIP graphs, which cannot carry event records between
@@ -174,13 +188,20 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     replayed = comm is None and B < 2048 and not all_stages and prefetch
     names = ('prep', 'scan', 'scatter', 'fwd', 'item', 'user', 'finish') if comm is None else ('fwd', 'item', 'user')
     if not replayed:
-        st.enable_timing(names if all_stages else ('fwd',), every=1 if (all_stages or steps <= 64) else 8)
+        # an event-timed launch costs the step ~10 us (measured: 210 / 206 / 202 us per step with every 1st / 2nd / 4th
+        # step timed over 20 steps): every 4th step of a short run, every 8th of a long one
+        every = int(os.environ.get('HSK_BENCH_EVERY', 0)) or (1 if all_stages else 4 if steps <= 64 else 8)
+        st.enable_timing(names if all_stages else ('fwd',), every=every)
+    ev_f0, ev_f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
     run(steps, warmup)
+    ev_f0.record()
     st.flush()   # lazily updated rows are brought up to date INSIDE the timed region: no work is skipped
+    ev_f1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    flush_us = ev_f0.elapsed_time(ev_f1) * 1e3
     st.disable_timing()
     if comm is not None:                                          # the slowest rank defines the step time
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -212,6 +233,7 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     out = dict(value=steps * B * N * world / elapsed, ms_per_step=elapsed * 1e3 / steps,
                fwd_us=(fwd_ms * 1e3 / fwd_n) if fwd_n else None, fwd_launches=int(fwd_n), loss=loss, B=B, N=N, D=D,
                data=data, csr=csr, nnz=nnz, steps=steps, warmup=warmup, graph_replays=n_replays, pure_us=pure_us,
+               flush_us=flush_us, flush_cadence=st.flush_cadence(B) if comm is None else st.flush_cadence(),
                lazy_users=bool(st.st.lazy_users) if comm is None else True,
                parts=(st.batch_columns(B, N + 1) - N) if comm is None else 1)
     if all_stages:
@@ -640,7 +662,12 @@ def main():
                    f'user rows, reduce_scatter of user-row gradients, 2 scalar-per-positive all_reduces; no table is replicated',
                    'lr': LR, 'wd': WD, 'loss_last_step': r['loss'],
                    'user_adamw': 'lazy, exact' if r['lazy_users'] else 'dense sweep',
-                   'steps_issued_as_replayed_graphs': 64 * r['graph_replays']},
+                   'steps_issued_as_replayed_graphs': 64 * r['graph_replays'],
+                   'warmup_steps_run': r['warmup']},
+        # the closing sweep of the lazily updated tables is inside the timed region: ms_per_step carries 1/steps of it
+        'flush_us_in_timed_region': r['flush_us'],
+        'ms_per_step_without_closing_flush': r['ms_per_step'] - r['flush_us'] * 1e-3 / args.steps,
+        'lazy_sweep_cadence_steps': [None if f >= (1 << 29) else f for f in r['flush_cadence']],
         'roofline': roofline_of(args.workload, r),
     }
     if comm is not None:

@@ -102,6 +102,7 @@ SIGNATURES = {
     'hsk_aux_create': (c_void_p, []),
     'hsk_aux_destroy': (None, [c_void_p]),
     'hsk_bprmf_hint_next': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
+    'hsk_bprmf_hint_after_run': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
     'hsk_shard_workspace_bytes': (c_int64, [c_int64] * 4),
     'hsk_shard_init': (c_int, [POINTER(HskBprmfShard), c_void_p]),
     'hsk_shard_prepare': (c_int, [POINTER(HskBprmfShard), c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p]),

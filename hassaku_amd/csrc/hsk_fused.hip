@@ -388,6 +388,10 @@ struct hsk_aux {
   bool hint_valid = false;
   const int64_t* hint_order = nullptr;
   int64_t hint_start = 0, hint_batch = 0, hint_nneg = 0;
+  // the batch that follows the next hsk_bprmf_train_steps run (hsk_bprmf_hint_after_run): hinted by the run's last step
+  bool tail_valid = false;
+  const int64_t* tail_order = nullptr;
+  int64_t tail_start = 0, tail_batch = 0, tail_nneg = 0;
   bool pf_valid = false;  // a prefetched batch sits in set `cur_set ^ 1`
   const int64_t* pf_order = nullptr;
   int64_t pf_start = 0, pf_batch = 0, pf_nneg = 0, pf_step = 0;
@@ -460,6 +464,23 @@ extern "C" int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, in
   a->hint_start = start;
   a->hint_batch = batch;
   a->hint_nneg = n_neg;
+  return HSK_OK;
+}
+
+extern "C" int hsk_bprmf_hint_after_run(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
+                                        int64_t n_neg) {
+  HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
+  hsk_aux* a = (hsk_aux*)st->aux;
+  HSK_REQUIRE(a != nullptr, HSK_ERR_INVALID, "hint_after_run needs an aux handle in the state");
+  a->tail_valid = false;
+  if (batch <= 0) return HSK_OK;
+  HSK_REQUIRE(batch <= st->max_batch && n_neg >= 1 && n_neg + 1 <= st->max_cols && start >= 0 && start + batch <= st->nnz,
+              HSK_ERR_INVALID, "hint_after_run: batch outside the workspace limits / the interactions");
+  a->tail_valid = true;
+  a->tail_order = order;
+  a->tail_start = start;
+  a->tail_batch = batch;
+  a->tail_nneg = n_neg;
   return HSK_OK;
 }
 
@@ -767,13 +788,14 @@ static bool hsk_prefetch_wanted(const hsk_bprmf_state* st) {
 
 // fork_recorded: ev_fork already rides on the forward kernel's completion signal (hipExtLaunchKernelGGL stop event),
 // which saves the separate barrier packet a hipEventRecord would put between the forward and the item pass
+// fork_on: the event to fork on when it is not aux->ev_fork (a timed step: the stop event of the timed forward launch)
 static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set, hipStream_t stream,
-                               bool fork_recorded = false) {
+                               bool fork_recorded = false, hipEvent_t fork_on = nullptr) {
   hsk_aux* aux = (hsk_aux*)st->aux;
   if (!hsk_prefetch_wanted(st)) return HSK_OK;
   const hsk_ws wn = hsk_select(w_all, set ^ 1);
   if (!fork_recorded) HSK_HIP(hipEventRecord(aux->ev_fork, stream));
-  HSK_HIP(hipStreamWaitEvent(aux->side, aux->ev_fork, 0));
+  HSK_HIP(hipStreamWaitEvent(aux->side, fork_on ? fork_on : aux->ev_fork, 0));
   int prc = hsk_launch_prep_sample(st, wn, aux->hint_order, aux->hint_start, aux->hint_batch, aux->hint_nneg,
                                    aux->g_desc ? (uint64_t)(aux->g_rel + 1) : (uint64_t)st->step, aux->side);
   if (!prc) {
@@ -844,6 +866,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   const bool late_fork = !hsk_pf_early(B) && hsk_prefetch_wanted(st);
   hipEvent_t fork_ev = (late_fork && !capturing) ? aux->ev_fork : nullptr;
 
+  hipEvent_t timed_fwd_end = nullptr;   // a timed step: the forward launch's stop event doubles as the fork event
   int rc = hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
     constexpr int V = decltype(v_)::value;
     constexpr int NCH = decltype(n_)::value;
@@ -886,6 +909,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       if (!fwd_beg || !fwd_end) return HSK_ERR_HIP;
       tm->beg[HSK_STAGE_FWD].push_back(fwd_beg);
       tm->end[HSK_STAGE_FWD].push_back(fwd_end);
+      timed_fwd_end = fwd_end;
     }
 #define HSK_LAUNCH_FWD(LK)                                                                                          \
   if (capturing)                                                                                                    \
@@ -979,8 +1003,9 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   HSK_LAUNCH_CHECK();
 
   if (late_fork) {
-    const bool fork_on_kernel = !capturing && !(st->timing && st->timing_now && ((st->timing_mask >> HSK_STAGE_FWD) & 1));
-    int prc = hsk_launch_prefetch(st, w_all, set, stream, fork_on_kernel);
+    // the fork rides on the forward launch's own stop event: aux->ev_fork, or (timed step) the timing event
+    const bool fork_on_kernel = !capturing;
+    int prc = hsk_launch_prefetch(st, w_all, set, stream, fork_on_kernel, timed_fwd_end);
     if (prc) return prc;
   }
 
@@ -1360,14 +1385,19 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
         return rc;
     }
   }
+  hsk_aux* tail_aux = (hsk_aux*)st->aux;
   for (; s < n_steps; ++s) {
     if (st->aux && s + 1 < n_steps) {
       int hrc = hsk_bprmf_hint_next(st, order, start + (s + 1) * batch, batch, n_neg);
+      if (hrc) return hrc;
+    } else if (tail_aux && tail_aux->tail_valid) {   // the run's last step prepares the batch the caller named
+      int hrc = hsk_bprmf_hint_next(st, tail_aux->tail_order, tail_aux->tail_start, tail_aux->tail_batch, tail_aux->tail_nneg);
       if (hrc) return hrc;
     }
     int rc = hsk_bprmf_train_step_sampled(st, order, start + s * batch, batch, n_neg, stream_);
     if (rc) return rc;
   }
+  if (tail_aux) tail_aux->tail_valid = false;
   return HSK_OK;
 }
 

@@ -481,6 +481,15 @@ class BprMfFusedState:
         _lib.check(self.lib.hsk_bprmf_hint_next(ctypes.byref(self.st), _p(order), start, batch, n_neg),
                    'hsk_bprmf_hint_next')
 
+    def hint_after_run(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int):
+        """Name the batch that follows the NEXT steps_sampled() run: its last step prepares it on the side stream, so
+        an epoch issued in several runs keeps its prefetch pipeline full.  No-op without overlap=True."""
+        if self._aux is None:
+            return
+        self._hint_order = order
+        _lib.check(self.lib.hsk_bprmf_hint_after_run(ctypes.byref(self.st), _p(order), start, batch, n_neg),
+                   'hsk_bprmf_hint_after_run')
+
     def last_batch(self, batch: int, n_cols: int):
         u = torch.empty(batch, dtype=torch.int64, device=self.device)
         i = torch.empty((batch, n_cols), dtype=torch.int64, device=self.device)

@@ -223,6 +223,8 @@ class Trainer:
                 if k + run < len(batches) and run == 1:
                     fused.hint_next(*batches[k + 1], n_neg)
                 if run > 1:
+                    if k + run < len(batches):            # the run's last step prepares the next run's first batch
+                        fused.hint_after_run(*batches[k + run], n_neg)
                     fused.steps_sampled(order, start, run, nb, n_neg)
                 else:
                     fused.step_sampled(order, start, nb, n_neg)

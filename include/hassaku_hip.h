@@ -318,6 +318,13 @@ int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, int64_t start
 int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t n_steps, int64_t batch,
                           int64_t n_neg, hsk_stream_t stream);
 
+/* Name the batch that FOLLOWS the next hsk_bprmf_train_steps run (the first batch of the caller's next run): the run's
+ * last step then prepares it on the side stream, as every other step of the run does for its successor -- an epoch
+ * loop issued in several runs (data/dataloader.py:92-129 feeding train/trainer.py:127-160) keeps its prefetch pipeline
+ * full across the calls.  Same rules as hsk_bprmf_hint_next; consumed by (and cleared after) the next run; ignored by
+ * runs replayed as graphs, which prepare their first batch themselves.  batch <= 0 clears it. */
+int hsk_bprmf_hint_after_run(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch, int64_t n_neg);
+
 /* number of runs hsk_bprmf_train_steps has issued as replayed graphs so far (0 when every step was launched eagerly) */
 int64_t hsk_bprmf_graph_replays(const hsk_bprmf_state* st);
 
