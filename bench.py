@@ -444,6 +444,17 @@ class _EvalData:
         return self._arr
 
 
+def eval_problem(shape, device):
+    """(user_emb, item_emb, item_bias, dataset) of one evaluation leg -- also what tests/test_hip_parity.py pins against
+    the oracle (test_bench_eval_pass_vs_oracle): the pass the bench times is the pass the test checks."""
+    U, I, D, npos = EVAL_SHAPES[shape]
+    torch.manual_seed(0)
+    user_emb = torch.randn(U, D, device=device) * 0.05
+    item_emb = torch.randn(I, D, device=device) * 0.05
+    item_bias = torch.randn(I, device=device) * 0.1
+    return user_emb, item_emb, item_bias, _EvalData(U, I, npos, device)
+
+
 def run_eval(shape, device, comm=None, chunk=None, repeat=3):
     """Full-catalogue evaluation (scores U x I^T, exclusion mask, top-100, precision/recall/ndcg at 100/50/10/5).
     comm None: one GPU.  Otherwise ITEM-SHARDED over the ranks on physically sliced tables (dist.evaluate_item_sharded)."""
@@ -452,11 +463,7 @@ def run_eval(shape, device, comm=None, chunk=None, repeat=3):
     U, I, D, npos = EVAL_SHAPES[shape]
     if chunk is None:     # (wide catalogue: top-k inside the GEMM; narrow: materialised scores, 0.7 GB of them per chunk at ml10m)
         chunk = 16384
-    torch.manual_seed(0)
-    user_emb = torch.randn(U, D, device=device) * 0.05
-    item_emb = torch.randn(I, D, device=device) * 0.05
-    item_bias = torch.randn(I, device=device) * 0.1
-    ds = _EvalData(U, I, npos, device)
+    user_emb, item_emb, item_bias, ds = eval_problem(shape, device)
     ev = FullEvaluator(aggr_by_group=True, n_groups=0, user_to_user_group=None)
     ks = sorted(ev.K_VALUES, reverse=True)
     world = 1 if comm is None else comm.world
@@ -566,6 +573,26 @@ def cpu_baseline(headline, budget_s):
             'sample': f'{steps} steps of B={B} x N={N} (D={D}, {headline} shape) in {secs:.1f}s, torch CPU ops on '
                       f'{cores} threads + numpy rejection sampler, 0 loader workers',
             'legs': legs}
+
+
+def run_sharded_1rank(workload, device):
+    import torch.distributed as dist
+    from hassaku_amd.dist import Comm
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    dist.init_process_group('nccl', device_id=device)
+    try:
+        comm = Comm()
+        x = run_training(workload, device, 200, 20, comm=comm)
+        ev = run_eval('lfm2b', device, comm)
+        return {'workload': workload_name(workload, x) + '; ShardedBprMf on a 1-rank RCCL group (hsk_shard_step: the '
+                                                          'whole step from one C call, collectives on the library\'s own communicator)',
+                'value': x['value'], 'unit': 'triplets/s', 'steps': 200, 'warmup': 20, 'ms_per_step': x['ms_per_step'],
+                'fwd_us': x['fwd_us'], 'loss_last_step': x['loss'],
+                'eval_lfm2b_item_sharded_users_per_s': ev['users_per_s']}
+    finally:
+        dist.destroy_process_group()
 
 
 def guarded(fn, *a):
@@ -692,6 +719,9 @@ def main():
             out['eval'] = {s: run_eval(s, device) for s in ('ml10m', 'lfm2b')}
             # BASELINE configs[4] needs 8 GPUs; what one GPU can show is one rank's full-size share of it
             out['workloads']['cfg5_shard'] = guarded(run_cfg5, device, 12, 4)
+            # the multi-GPU code path on this one GPU (a 1-rank RCCL group: every kernel, every collective call and
+            # stream hand-off of the sharded step, no link traffic): what the step costs before any xGMI link is involved
+            out['sharded_1rank'] = guarded(run_sharded_1rank, args.workload, device)
         else:
             out['eval'] = {'lfm2b': run_eval('lfm2b', device, comm)}
             if world == CFG5['world']:     # the one place the whole configs[4] job can run

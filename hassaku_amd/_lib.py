@@ -115,6 +115,15 @@ SIGNATURES = {
     'hsk_shard_apply_users': (c_int, [POINTER(HskBprmfShard), c_void_p]),
     'hsk_shard_flush': (c_int, [POINTER(HskBprmfShard), c_void_p]),
     'hsk_shard_last_batch': (c_int, [POINTER(HskBprmfShard), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hsk_rccl_available': (c_int, []),
+    'hsk_rccl_unique_id': (c_int, [c_void_p]),
+    'hsk_shard_rt_create': (c_void_p, [c_int32, c_int32, c_void_p]),
+    'hsk_shard_rt_destroy': (None, [c_void_p]),
+    'hsk_shard_step': (c_int, [POINTER(HskBprmfShard), c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                               c_void_p]),
+    'hsk_shard_rt_flush': (c_int, [POINTER(HskBprmfShard), c_void_p, c_void_p]),
+    'hsk_shard_rt_cur_set': (c_int, [c_void_p]),
+    'hsk_shard_rt_discard_prefetch': (c_int, [POINTER(HskBprmfShard), c_void_p, c_void_p]),
     'hsk_bprmf_flush': (c_int, [POINTER(HskBprmfState), c_void_p]),
     'hsk_bprmf_last_batch': (c_int, [POINTER(HskBprmfState), c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'hsk_mf_eval_topk': (c_int, [c_void_p] * 5 + [c_int64] * 3 + [c_void_p, c_int64, c_int64, c_int64,

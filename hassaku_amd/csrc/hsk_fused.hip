@@ -1493,6 +1493,7 @@ extern "C" int hsk_sample_negatives_uniform(const int64_t* csr_indptr, const int
 // multi-GPU phases (item table range-sharded, user table row-sharded)
 #include <algorithm>
 #include "hsk_shard.inc"
+#include "hsk_rccl.inc"
 
 // =============================================================================================
 // Generic embedding gather + its dense backward (the gather primitive the reference's other SGD models share:

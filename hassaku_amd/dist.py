@@ -360,6 +360,28 @@ class ShardedBprMf:
         self._ev_fork, self._ev_ready = torch.cuda.Event(), torch.cuda.Event()
         self._cur_set = 0
         self._pf = None          # (order ptr, start, batch, step index it is for, set, order tensor kept alive)
+        self._prefetch = bool(prefetch)
+        # Backend nccl: the whole step is issued from ONE C call with the collectives called on RCCL directly
+        # (csrc/hsk_rccl.inc: hsk_shard_step) -- the phase-by-phase sequence below costs ten Python / torch dispatches
+        # per step and leaves the GPU idle in between.  The library opens its own communicator over the same ranks; the
+        # 128-byte id travels through this process group.  HSK_SHARD_NATIVE=0 keeps the phased path (same results).
+        self._rt = None
+        self._order_keep = None
+        import os
+        if isinstance(comm, Comm) and comm.native and os.environ.get('HSK_SHARD_NATIVE', '1') != '0' \
+                and self.lib.hsk_rccl_available():
+            idb = torch.zeros(128, dtype=torch.uint8)
+            if r == 0:
+                buf = (ctypes.c_ubyte * 128)()
+                _lib.check(self.lib.hsk_rccl_unique_id(buf), 'hsk_rccl_unique_id')
+                idb = torch.tensor(list(buf), dtype=torch.uint8)
+            idd = idb.to(dev)
+            comm.broadcast(idd, src=0)
+            raw = bytes(idd.cpu().tolist())
+            rt = self.lib.hsk_shard_rt_create(W, r, ctypes.c_char_p(raw))
+            if not rt:
+                raise RuntimeError('hsk_shard_rt_create failed: ' + self.lib.hsk_last_error().decode('utf-8', 'replace'))
+            self._rt = ctypes.c_void_p(rt)
 
     @property
     def step_count(self) -> int:
@@ -394,6 +416,13 @@ class ShardedBprMf:
         main = torch.cuda.current_stream()
         s = main.cuda_stream
         ref = ctypes.byref(sh)
+        if self._rt is not None:
+            nxt = -1 if (next_start is None or not self._prefetch) else int(next_start)
+            _lib.check(lib.hsk_shard_step(ref, self._rt, _p(order), int(start_global), nb, self.n_neg, nxt,
+                                          0 if next_batch is None else int(next_batch), s), 'hsk_shard_step')
+            self._order_keep = order          # the prepared batch reads it during the next call
+            self._cur_set = int(lib.hsk_shard_rt_cur_set(self._rt))
+            return
         key = (_p(order), int(start_global), nb, self.step_count)
         if self._pf is not None and self._pf[:4] == key:
             main.wait_event(self._ev_ready)              # sampled + sorted during the previous step
@@ -426,6 +455,10 @@ class ShardedBprMf:
 
     def _discard_prefetch(self):
         """A prepared batch that the next call does not consume: give its owner map back."""
+        if self._rt is not None:
+            _lib.check(self.lib.hsk_shard_rt_discard_prefetch(ctypes.byref(self.sh), self._rt, _stream()),
+                       'hsk_shard_rt_discard_prefetch')
+            return
         if self._pf is None:
             return
         torch.cuda.current_stream().wait_event(self._ev_ready)
@@ -482,6 +515,19 @@ class ShardedBprMf:
     def flush(self):
         self._discard_prefetch()
         _lib.check(self.lib.hsk_shard_flush(ctypes.byref(self.sh), _stream()), 'hsk_shard_flush')
+
+    def close(self):
+        """Release the library's RCCL communicator and streams (collective in spirit: call it on every rank)."""
+        rt, self._rt = getattr(self, '_rt', None), None
+        if rt is not None:
+            torch.cuda.synchronize()
+            self.lib.hsk_shard_rt_destroy(rt)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def last_loss(self) -> float:
         t = self.loss_out[:1].clone()

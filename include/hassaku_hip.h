@@ -440,6 +440,31 @@ int hsk_shard_last_batch(const hsk_bprmf_shard* sh, int32_t set, int64_t batch, 
                          int32_t* u_out, hsk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The sharded step issued from ONE C call, the collectives called on RCCL directly (csrc/hsk_rccl.inc).
+ * The phase functions above leave the collectives to the caller (hassaku_amd/dist.py: torch.distributed), which costs
+ * ten host dispatches per step; hsk_shard_step enqueues the same kernels and ncclAllGather / ncclAllReduce /
+ * ncclReduceScatter between them -- the row exchanges on a communication stream, so that the preparation of the next
+ * batch and the item pass overlap them.  Same results as the phased sequence.  RCCL is loaded at run time (dlopen).
+ *   hsk_rccl_available      1 if librccl could be loaded
+ *   hsk_rccl_unique_id      rank 0: 128 bytes (host) that the caller hands to every rank by any transport
+ *   hsk_shard_rt_create     collective: every rank, same 128 bytes, its GPU current -> runtime handle (communicator,
+ *                           side / communication streams, the batch prepared a step ahead), NULL on failure
+ *   hsk_shard_step          one global step; next_start >= 0 names the following call's batch (prepared a step ahead;
+ *                           next_batch <= 0: same size); replaces pack .. apply_users of the phased protocol
+ *   hsk_shard_rt_flush      drops a prepared batch that was never trained on, then hsk_shard_flush
+ *   hsk_shard_rt_cur_set / _discard_prefetch   debug / parity (which buffer set the last step used)
+ * ------------------------------------------------------------------------------------------ */
+int hsk_rccl_available(void);
+int hsk_rccl_unique_id(void* id128);
+void* hsk_shard_rt_create(int32_t world, int32_t rank, const void* id128);
+void hsk_shard_rt_destroy(void* rt);
+int hsk_shard_step(hsk_bprmf_shard* sh, void* rt, const int64_t* order, int64_t start_global, int64_t batch,
+                   int64_t n_neg, int64_t next_start, int64_t next_batch, hsk_stream_t stream);
+int hsk_shard_rt_flush(hsk_bprmf_shard* sh, void* rt, hsk_stream_t stream);
+int hsk_shard_rt_cur_set(const void* rt);
+int hsk_shard_rt_discard_prefetch(hsk_bprmf_shard* sh, void* rt, hsk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Synthetic training interactions generated straight into HBM (BASELINE configs[4]: 100 M users x 10 M items; no CSV
  * is ever written).  Stands where TrainRecDataset._prepare_data builds the COO iteration matrix and the CSR sampling
  * matrix from listening_history_train.csv (data/dataset.py:120-131): same arrays, same invariants (CSR rows sorted and

@@ -213,7 +213,9 @@ def _cfg5_share_worker(rank, world, port, out_dir):
         tu.step(uu, gU, s, orc)
         ti.step(it_sorted[first], gI, s, orc)
         tb.step(it_sorted[first], gIb[:, None], s, orc)
-        sh.step_sampled(order, start, next_start=start + G if s < S else None)
+        # (no next_start: a batch named ahead has its user rows replayed ahead of time behind this step -- the host
+        # model above reads a row's state as of step 0 when it first meets it; test_dist.py covers the ahead path)
+        sh.step_sampled(order, start)
         got = sh.last_loss()
         assert abs(got - loss) <= 2e-5 * abs(loss), (s, got, loss)
     sh.flush()
@@ -223,7 +225,9 @@ def _cfg5_share_worker(rank, world, port, out_dir):
         assert_adam_param_close(p, t.P[0], name)
         for got_, ref_, what in ((m, t.P[1], 'exp_avg'), (v, t.P[2], 'exp_avg_sq')):
             scale = np.abs(ref_).max()
-            assert np.abs(got_ - ref_).max() <= 1e-5 * scale, (name, what)
+            err = np.abs(got_ - ref_)
+            assert err.max() <= 1e-5 * scale, (name, what, float(err.max()), float(scale), int((err > 1e-5 * scale).sum()),
+                                               int(np.argmax(err.max(axis=-1))), len(t.rows))
     # rows outside every batch: S zero-gradient steps = S multiplications by fl32(1 - lr*wd), moments exactly 0
     decay = np.float32(1.0 - lr * wd)
     for tab, key, rows, init, touched in ((sh.user_emb, 'user_emb', idle_u, init_u, tu.rows),

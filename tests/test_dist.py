@@ -358,6 +358,31 @@ def test_one_rank_rccl_sharded_step_equals_single_gpu_step(tmp_path):
     _check_against_single_gpu(tmp_path, 1, shape, 70)
 
 
+def _native_or_phased_worker(rank, world, port, out_dir, native):
+    os.environ['HSK_SHARD_NATIVE'] = '1' if native else '0'
+    os.makedirs(out_dir, exist_ok=True)
+    _shard_worker(rank, world, port, out_dir, 'nccl', dict(D=64, N=12), 70, 'auto', True)
+
+
+@pytest.mark.gpu
+def test_native_rccl_step_equals_phased_step_bitwise(tmp_path):
+    """hsk_shard_step (the whole step from one C call, ncclAllGather / ncclAllReduce / ncclReduceScatter on the
+    library's own communicator, exchanges on a communication stream) == the phase-by-phase sequence driven from Python
+    with torch.distributed: same kernels, same order -> the same bits (tables, losses, metrics), 70 steps with the
+    side-stream preparation and a wrong next-batch guess."""
+    from hassaku_amd import _lib
+    if not _lib.load().hsk_rccl_available():
+        pytest.skip('librccl not loadable')
+    res = []
+    for native in (True, False):
+        d = str(tmp_path / ('native' if native else 'phased'))
+        mp.spawn(_native_or_phased_worker, args=(1, _free_port(), d, native), nprocs=1, join=True)
+        res.append(np.load(os.path.join(d, 'mp.npz')))
+    for k in ('U', 'Ub', 'I', 'Ib', 'losses', 'metric_values'):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    _check_against_single_gpu(tmp_path / 'native', 1, dict(D=64, N=12), 70)
+
+
 @pytest.mark.gpu
 def test_two_rank_sharded_step_equals_single_gpu_step(tmp_path):
     shape = dict(D=64, N=12)

@@ -1037,3 +1037,57 @@ def test_score_all_fast_path_is_not_keyed_on_the_address():
     out = m.combine_user_item_representations(m.get_user_representations(u), m.get_item_representations(perm))
     assert torch.allclose(out, full[:, perm], rtol=1e-5, atol=1e-7), same_block
     assert not torch.equal(out, full)
+
+
+def test_bench_eval_pass_vs_oracle(ops, oracle):
+    """The evaluation pass bench.py TIMES (BASELINE configs[3] shape: 16 384 users x 131 072 items, D = 512, one
+    16 384-user chunk, top-100 selected inside the score GEMM, 120 excluded positives per user), value-checked against
+    the ORACLE (oracle.eval_scores + oracle.topk + oracle.rank_metrics, eval/eval.py:54-75,237-253 of the reference)
+    on a sample of its users -- and the same users through the 8 physical item shards + hsk_topk_merge."""
+    import bench
+    U, I, D, _ = bench.EVAL_SHAPES['lfm2b']
+    user_emb, item_emb, item_bias, ds = bench.eval_problem('lfm2b', torch.device('cuda'))
+    arr = ds.device_arrays('cuda')
+    ks = [100, 50, 10, 5]
+    u_all = torch.arange(U, device='cuda')
+    vals, ids, sc = ops.mf_eval_topk(user_emb, item_emb, item_bias, None, None, u_all, 100, arr['excl_indptr'],
+                                     arr['excl_indices'])
+    assert sc is None                                    # the fused path: no score matrix
+    met = ops.rank_metrics(ids, u_all, arr['label_indptr'], arr['label_indices'], ks).cpu().numpy()
+    sample = np.sort(np.random.RandomState(5).choice(U, size=96, replace=False))
+    sample[0], sample[-1] = 0, U - 1
+    Uh, Ih, Ibh = (t.cpu().numpy() for t in (user_emb, item_emb, item_bias))
+    eptr, eidx = ds.exclude_csr.indptr, ds.exclude_csr.indices
+    ref = oracle.eval_scores(Uh, Ih, Ibh, None, None, sample, eptr, eidx)
+    rv, ri = oracle.topk(ref, 101)
+    scale = np.abs(rv[:, :100]).max()
+
+    def check(v, i, what):
+        v, i = v.cpu().numpy(), i.cpu().numpy().astype(np.int64)
+        assert np.abs(v - rv[:, :100]).max() <= 1e-5 * scale, what
+        gap = (rv[:, :-1] - rv[:, 1:]) > 2e-5 * scale    # ranks whose neighbours fp32 sums can tell apart
+        clear = gap[:, :100] & np.concatenate([np.ones((len(sample), 1), bool), gap[:, :99]], axis=1)
+        assert clear.mean() > 0.9, what
+        assert np.array_equal(i[clear], ri[:, :100][clear]), what
+        # never an excluded item, never a duplicate
+        for r, uu in enumerate(sample):
+            assert not np.isin(i[r], eidx[eptr[uu]:eptr[uu + 1]]).any() and len(np.unique(i[r])) == 100, what
+
+    sel = torch.from_numpy(sample).cuda()
+    check(vals[sel], ids[sel], 'fused pass')
+    ref_met = oracle.rank_metrics(ri[:, :100], sample, ds.label_csr.indptr, ds.label_csr.indices, ks)
+    unambiguous = np.array([np.array_equal(ids[u].cpu().numpy(), ri[r, :100]) for r, u in enumerate(sample)])
+    assert unambiguous.mean() > 0.5
+    np.testing.assert_allclose(met[sample][unambiguous], ref_met[unambiguous], rtol=1e-6, atol=1e-7)
+    # the 8 physical item shards of an 8-GPU node (global ids, mask restricted to the range) + the merge
+    W = 8
+    pv, pi = [], []
+    for r in range(W):
+        lo, hi = I * r // W, I * (r + 1) // W
+        v, i, _ = ops.mf_eval_topk(user_emb, item_emb[lo:hi].contiguous(), item_bias[lo:hi].contiguous(), None, None, sel, 100,
+                                   arr['excl_indptr'], arr['excl_indices'], item_begin=lo, item_count=hi - lo,
+                                   item_shard=True, n_items_global=I)
+        pv.append(v)
+        pi.append(i)
+    mv, mi = ops.topk_merge(torch.stack(pv).contiguous(), torch.stack(pi).contiguous())
+    check(mv, mi, '8-shard merge')

@@ -5,7 +5,7 @@ import csv
 import glob
 import sys
 
-p = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+p = sorted(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True))[-1]
 anchor = sys.argv[2] if len(sys.argv) > 2 else 'k_fwd_ugrad'
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 rows = list(csv.DictReader(open(p)))
