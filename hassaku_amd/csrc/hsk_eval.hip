@@ -207,6 +207,7 @@ __device__ __forceinline__ void hsk_split3(float x, __bf16& h, __bf16& m, __bf16
 // consecutive elements (D % 4 == 0, 16-byte aligned rows).  The GEMM loops then only move 16-byte chunks global ->
 // registers -> LDS: the split (two roundings and two subtractions per element, per tile, in every workgroup) was a sixth
 // of the loop (profiles/probes/gemm_bf16x3.hip: 640 -> 545 us at the ml10m eval shape, 575 with this pre-pass).
+template <int TK>   // depth of a k-tile: 32 ([k-tile][row][piece][32], the 128 x 128 kernels) or 16 (k_score_gemm_x3_wide)
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ src, const int64_t* __restrict__ idx,
                                                       long long row0, long long n_src_rows, int n_valid, int n_pad, int D,
                                                       int Dp, __bf16* __restrict__ planes) {
@@ -229,21 +230,29 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
     hsk_split3(v[e], x1, x2, x3);
     p1[e] = x1; p2[e] = x2; p3[e] = x3;
   }
-  __bf16* dst = planes + ((long long)(k / GEMM_BK) * n_pad + r) * 96 + (k % GEMM_BK);
+  __bf16* dst = planes + ((long long)(k / TK) * n_pad + r) * (3 * TK) + (k % TK);
   *reinterpret_cast<hsk_bf16x4*>(dst) = p1;
-  *reinterpret_cast<hsk_bf16x4*>(dst + 32) = p2;
-  *reinterpret_cast<hsk_bf16x4*>(dst + 64) = p3;
+  *reinterpret_cast<hsk_bf16x4*>(dst + TK) = p2;
+  *reinterpret_cast<hsk_bf16x4*>(dst + 2 * TK) = p3;
 }
 
 // (also used by hsk_eval_fused.hip)  planes: 6 * n_pad * Dp bytes, Dp = dim rounded up to 32
+static void hsk_eval_split_planes_k(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
+                                    int n_pad, int D, void* planes, hipStream_t stream, int tile_k) {
+  const int Dp = (int)hsk_align_up(D, GEMM_BK);
+  const unsigned nblk = (unsigned)hsk_ceil_div((long long)n_pad * (Dp / 4), 256);
+  if (tile_k == 16)
+    k_split_planes<16><<<nblk, 256, 0, stream>>>(src, idx, row0, n_src_rows, n_valid, n_pad, D, Dp, (__bf16*)planes);
+  else
+    k_split_planes<GEMM_BK><<<nblk, 256, 0, stream>>>(src, idx, row0, n_src_rows, n_valid, n_pad, D, Dp, (__bf16*)planes);
+}
 void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
                            int n_pad, int D, void* planes, hipStream_t stream) {
-  const int Dp = (int)hsk_align_up(D, GEMM_BK);
-  k_split_planes<<<(unsigned)hsk_ceil_div((long long)n_pad * (Dp / 4), 256), 256, 0, stream>>>(
-      src, idx, row0, n_src_rows, n_valid, n_pad, D, Dp, (__bf16*)planes);
+  hsk_eval_split_planes_k(src, idx, row0, n_src_rows, n_valid, n_pad, D, planes, stream, GEMM_BK);
 }
 
 typedef unsigned hsk_vu32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 structs ends up in scratch)
+typedef float hsk_f32x4 __attribute__((ext_vector_type(4)));
 
 // PLANES: Apl / Bpl hold the operands' pieces (k_split_planes; a_rows / b_rows = their padded row counts)
 template <bool VEC4, bool PLANES = false>
@@ -431,6 +440,206 @@ __global__ __launch_bounds__(256, 2) void k_score_gemm_x3(const float* __restric
         }
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same GEMM on a 256 x 256 block tile, ONE wave per SIMD (profiles/probes/gemm_bf16x3_v4.hip).
+//
+// The 128 x 128 tiling above moves 6 bytes per operand element through the L2s for 128 flop per byte -- at the bf16
+// MFMA peak 19.5 TB/s, more than the L2s deliver -- and its two workgroups per CU share every SIMD's matrix pipe.
+// Here a workgroup owns 256 x 256 (256 flop/B), its four waves 128 x 128 each (4 x 4 accumulator tiles = 256 AGPRs,
+// 0.25 fragment reads per MFMA), alone on their SIMDs.  The pieces ([k16-tile][row][piece][16] bf16 from
+// k_split_planes<16>, rows padded to 256 with zeros) go global -> registers -> LDS one k-step ahead, LDS double-buffered
+// at BK = 16, one barrier per k-step.  What made the difference in the probe was the ORDER of a step's instructions: its
+// 12 LDS stores + 12 global loads as a burst at the head of the step held the wave -- and its SIMD's matrix pipe -- for
+// ~1500 of the step's ~5000 cycles (the CU's L1 takes 64 B per clock, the LDS store path 13 cycles per 16-byte store);
+// the compiler left to itself clusters them (the scheduling-group hints did not move it).  The step is therefore written
+// as ONE hand-interleaved stream pinned by scheduling fences: a (store, load) pair after every 8 MFMAs, the fragment
+// reads of term n+1 under the MFMAs of term n.  Probe, 8192 x 10752 x 512 on one box: 585 us (128 x 128, two workgroups
+// per CU) -> 451 us, 39 cycles per MFMA against the pipe's 32 -- at an in-kernel clock the chip lowers to 1.7 GHz under
+// this load (2.0-2.1 GHz under the looser loop): what bounds it now is power, not issue.
+// Every output element sees the same sequence of MFMAs as in k_score_gemm_x3: the scores are bit-identical.
+// ---------------------------------------------------------------------------------------------
+#define GEMM_W_BM 256
+#define GEMM_W_BN 256
+#define GEMM_W_BK 16
+#define GEMM_W_LDK (GEMM_W_BK + 8)   // 48-byte LDS rows: ds_read_b128 conflict-free
+#define GEMM_W_LDS_BYTES (2 * 3 * (GEMM_W_BM + GEMM_W_BN) * GEMM_W_LDK * 2)
+
+__global__ __launch_bounds__(256, 1) void k_score_gemm_x3_wide(const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                               const float* __restrict__ gb, int n_users, int Dp,
+                                                               const int64_t* __restrict__ u_idx, int n_rows,
+                                                               long long item_begin, int item_count,
+                                                               float* __restrict__ C, int32_t* status,
+                                                               const __bf16* __restrict__ Apl,
+                                                               const __bf16* __restrict__ Bpl, int a_rows, int b_rows) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 wlds[];
+  constexpr int BM = GEMM_W_BM, BN = GEMM_W_BN, LDK = GEMM_W_LDK, TM = 4, TN = 4, WM = 128, WN = 128;
+  constexpr int A_STAGE = 3 * BM * LDK, B_STAGE = 3 * BN * LDK;
+  __bf16* As = wlds;
+  __bf16* Bs = wlds + 2 * A_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int r32 = lane & 31, h = lane >> 5;
+  hsk_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  constexpr int CA = BM * 6 / 256, CB = BN * 6 / 256;   // 16-byte chunks of a tile per thread
+  hsk_vu32x4 ra[CA], rb[CB];
+  int offa[CA], offb[CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int c = tid + 256 * i, r = c / 6, j = c - r * 6;
+    offa[i] = (j >> 1) * (BM * LDK) + r * LDK + (j & 1) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int c = tid + 256 * i, r = c / 6, j = c - r * 6;
+    offb[i] = (j >> 1) * (BN * LDK) + r * LDK + (j & 1) * 8;
+  }
+  const int NT = Dp / GEMM_W_BK;
+  {   // tile 0 -> LDS buffer 0, tile 1 -> registers
+    const __bf16* a = Apl + (long long)m0 * 48;
+    const __bf16* b = Bpl + (long long)n0 * 48;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const hsk_vu32x4*>(a + (tid + 256 * i) * 8);
+#pragma unroll
+    for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const hsk_vu32x4*>(b + (tid + 256 * i) * 8);
+#pragma unroll
+    for (int i = 0; i < CA; ++i) *reinterpret_cast<hsk_vu32x4*>(As + offa[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) *reinterpret_cast<hsk_vu32x4*>(Bs + offb[i]) = rb[i];
+    const int t1 = NT > 1 ? 1 : 0;
+    a = Apl + ((long long)t1 * a_rows + m0) * 48;
+    b = Bpl + ((long long)t1 * b_rows + n0) * 48;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const hsk_vu32x4*>(a + (tid + 256 * i) * 8);
+#pragma unroll
+    for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const hsk_vu32x4*>(b + (tid + 256 * i) * 8);
+  }
+  __syncthreads();
+  for (int t = 0; t < NT; ++t) {
+    const int buf = t & 1;
+    // (unconditional stores / loads, the tile index clamped: the last steps re-load the last tile and store into a buffer
+    // nobody reads any more -- branches would cut the step into basic blocks)
+    const __bf16* as = As + buf * A_STAGE + (wm * WM + r32) * LDK + 8 * h;
+    const __bf16* bs = Bs + buf * B_STAGE + (wn * WN + r32) * LDK + 8 * h;
+    const int tl = t + 2 < NT ? t + 2 : NT - 1;
+    const __bf16* ga = Apl + ((long long)tl * a_rows + m0) * 48;
+    const __bf16* gbp = Bpl + ((long long)tl * b_rows + n0) * 48;
+    __bf16* sa = As + (buf ^ 1) * A_STAGE;
+    __bf16* sb = Bs + (buf ^ 1) * B_STAGE;
+    hsk_bf16x8 a[3][TM], b[3][TN];
+    auto read_a = [&](int pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const hsk_bf16x8*>(as + pl * (BM * LDK) + i * 32 * LDK);
+    };
+    auto read_b = [&](int pl) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[pl][j] = *reinterpret_cast<const hsk_bf16x8*>(bs + pl * (BN * LDK) + j * 32 * LDK);
+    };
+    // the six products of weight >= 2^-16, smallest first: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int PER = TM * TN, NPAIR = CA + CB, CH = 6 * PER / NPAIR;   // 8 MFMAs per (store, load) pair
+    static_assert(6 * PER % NPAIR == 0 && PER % CH == 0, "chunking");
+    read_a(TA[0]);
+    read_b(TB[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NPAIR; ++c) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int m = c * CH + q, tt = m / PER, i = (m % PER) / TN, j = m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[tt]][i], b[TB[tt]][j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 0) read_a(TA[1]);             // term 1 needs a[0], b[2]; term 2 a[1], b[1]; terms 3..5 reuse
+      if (c == 1) read_b(TB[1]);
+      if (c == PER / CH) read_a(TA[2]);
+      if (c == PER / CH + 1) read_b(TB[2]);
+      if (c < CA) {
+        *reinterpret_cast<hsk_vu32x4*>(sa + offa[c]) = ra[c];
+        ra[c] = *reinterpret_cast<const hsk_vu32x4*>(ga + (tid + 256 * c) * 8);
+      } else {
+        *reinterpret_cast<hsk_vu32x4*>(sb + offb[c - CA]) = rb[c - CA];
+        rb[c - CA] = *reinterpret_cast<const hsk_vu32x4*>(gbp + (tid + 256 * (c - CA)) * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // Epilogue through LDS.  One workgroup per CU: nothing covers this phase, so its length counts in full -- and as
+  // dword-per-lane stores (256 per wave, every 128-byte piece split over two cache lines when the row stride is not a
+  // multiple of 32 floats: item_count = 10 677) it took about a quarter of the kernel at the ml10m shape.  Per band of
+  // 32 rows the four waves put their accumulators into LDS -- biases added in the reference's order (+= u_bias, +=
+  // i_bias, += global_bias), each row shifted by its own misalignment (row * item_count + n0) mod 4 so that 16-byte
+  // pieces of LDS are 16-byte pieces of global memory -- and every wave then writes 16 whole rows of the band's 256
+  // columns with one ds_read_b128 + one global_store_dwordx4 per lane and row; the ragged ends go out as dwords.
+  constexpr int LDR = 256 + 8;                       // floats per staged row (shift <= 3, 16-byte chunks conflict-free)
+  float* st = reinterpret_cast<float*>(wlds);        // 2 x 32 rows of LDR floats = 67.6 KB (the operand stages are dead)
+  const float gbv = gb ? gb[0] : 0.f;
+  const int ncols = min(256, item_count - n0);       // valid columns of this block
+  const int ic3 = item_count & 3;
+  float ibv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WN + j * 32 + r32;
+    ibv[j] = (Ib && col < item_count) ? Ib[item_begin + col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();   // the previous band's rows have been read (first band: the last k-step's fragments)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int rloc = (q & 3) + 8 * (q >> 2) + 4 * h;
+      const int row = m0 + wm * WM + i * 32 + rloc;
+      float ub = 0.f;
+      if (row < n_rows) {
+        long long uu = u_idx[row];
+        if (uu < 0 || uu >= n_users) {
+          if (status) atomicOr(status, HSK_STATUS_BAD_INDEX);
+          uu = 0;
+        }
+        if (Ub) ub = Ub[uu];
+      }
+      const int shift = ((row & 3) * ic3) & 3;       // (row * item_count + n0) mod 4, n0 a multiple of 256
+      float* dst = st + (wm * 32 + rloc) * LDR + wn * WN + r32 + shift;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float o = acc[i][j][q];
+        if (Ub) o += ub;
+        if (Ib) o += ibv[j];
+        if (gb) o += gbv;
+        dst[j * 32] = o;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int rloc = wn * 16 + rr;
+      const int row = m0 + wm * WM + i * 32 + rloc;
+      if (row >= n_rows) break;                      // wave-uniform
+      const int shift = ((row & 3) * ic3) & 3;
+      const float* src = st + (wm * 32 + rloc) * LDR;
+      float* gdst = C + (long long)row * item_count + n0 - shift;   // 16-byte aligned
+      const int f0 = 4 * lane;                       // this lane's chunk: staged floats [f0, f0 + 4) -> gdst[f0 ..]
+      const hsk_f32x4 v = *reinterpret_cast<const hsk_f32x4*>(src + f0);
+      const int lo = shift, hi = shift + ncols;      // valid staged floats
+      if (f0 >= lo && f0 + 4 <= hi) {
+        *reinterpret_cast<hsk_f32x4*>(gdst + f0) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (f0 + e >= lo && f0 + e < hi) gdst[f0 + e] = v[e];
+      }
+      if (lane < shift && 256 + lane < hi) gdst[256 + lane] = src[256 + lane];   // the chunk past lane 63
+    }
+  }
 }
 
 // excluded (user, item) pairs -> -inf.  One wave per eval row, lanes stride over the user's CSR row.
@@ -893,7 +1102,8 @@ static int hsk_launch_topk_i32(const float* X, int64_t rows, int64_t cols, int64
 extern "C" int64_t hsk_mf_eval_planes_bytes(int64_t n_rows, int64_t item_count, int64_t dim) {
   if (n_rows <= 0 || item_count <= 0 || dim <= 0) return 0;
   const int64_t Dp = hsk_align_up(dim, GEMM_BK);
-  return hsk_align_up(6 * hsk_align_up(n_rows, GEMM_BM) * Dp, 256) + hsk_align_up(6 * hsk_align_up(item_count, GEMM_BN) * Dp, 256);
+  // (rows padded to 256: what the widest block tile, k_score_gemm_x3_wide, reads)
+  return hsk_align_up(6 * hsk_align_up(n_rows, GEMM_W_BM) * Dp, 256) + hsk_align_up(6 * hsk_align_up(item_count, GEMM_W_BN) * Dp, 256);
 }
 
 extern "C" int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, const float* item_bias,
@@ -938,16 +1148,36 @@ extern "C" int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_
       planes_bytes >= hsk_mf_eval_planes_bytes(n_rows, item_count, dim)) {
     // the operands' bf16 pieces, made once for the call
     const int64_t Dp = hsk_align_up(dim, GEMM_BK);
-    const int a_rows = (int)hsk_align_up(n_rows, GEMM_BM), b_rows = (int)hsk_align_up(item_count, GEMM_BN);
+    const int a_rows = (int)hsk_align_up(n_rows, GEMM_W_BM), b_rows = (int)hsk_align_up(item_count, GEMM_W_BN);
     __bf16* Apl = (__bf16*)planes_ws;
     __bf16* Bpl = (__bf16*)((char*)planes_ws + hsk_align_up(6 * (int64_t)a_rows * Dp, 256));
-    hsk_eval_split_planes(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, Apl, stream);
-    hsk_eval_split_planes(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, Bpl, stream);
+    // 256 x 256 block tiles (one wave per SIMD) once there are enough of them to fill the chip a few times over;
+    // below that the 128 x 128 kernel, whose four times as many workgroups fill it sooner.  Same bits either way.
+    static const int wide_on = getenv("HSK_EVAL_WIDE") ? atoi(getenv("HSK_EVAL_WIDE")) : 1;
+    const int64_t wide_blocks = hsk_ceil_div(n_rows, GEMM_W_BM) * hsk_ceil_div(item_count, GEMM_W_BN);
+    const bool wide = wide_on == 2 || (wide_on && wide_blocks >= 3 * 256);
+    hsk_eval_split_planes_k(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, Apl, stream, wide ? 16 : GEMM_BK);
+    hsk_eval_split_planes_k(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, Bpl, stream,
+                            wide ? 16 : GEMM_BK);
     HSK_LAUNCH_CHECK();
-    k_score_gemm_x3<true, true><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias,
-                                                         (int)n_users, (int)dim, u_idx, (int)n_rows,
-                                                         (long long)item_begin, (int)item_count, scores_ws, status, Apl,
-                                                         Bpl, a_rows, b_rows);
+    if (wide) {
+      static bool lds_set = false;
+      if (!lds_set) {
+        HSK_HIP(hipFuncSetAttribute((const void*)k_score_gemm_x3_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GEMM_W_LDS_BYTES));
+        lds_set = true;
+      }
+      dim3 wgrid((unsigned)hsk_ceil_div(item_count, GEMM_W_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_W_BM));
+      k_score_gemm_x3_wide<<<wgrid, 256, GEMM_W_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, (int)n_users,
+                                                                     (int)Dp, u_idx, (int)n_rows, (long long)item_begin,
+                                                                     (int)item_count, scores_ws, status, Apl, Bpl, a_rows,
+                                                                     b_rows);
+    } else {
+      k_score_gemm_x3<true, true><<<grid, 256, 0, stream>>>(user_emb, item_emb, item_bias, user_bias, global_bias,
+                                                           (int)n_users, (int)dim, u_idx, (int)n_rows,
+                                                           (long long)item_begin, (int)item_count, scores_ws, status, Apl,
+                                                           Bpl, a_rows, b_rows);
+    }
   } else if (x3) {
     if (vec4) HSK_SCORE_GEMM(k_score_gemm_x3<true>); else HSK_SCORE_GEMM(k_score_gemm_x3<false>);
   } else {

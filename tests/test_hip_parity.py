@@ -672,7 +672,10 @@ def test_fused_topk_equals_materialised_topk(ops, shape):
     _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross=True)
 
 
-@pytest.mark.parametrize('shape', [(300, 300, 5000, 512, 100), (257, 400, 1300, 128, 5), (64, 64, 129, 16, 100)])
+@pytest.mark.parametrize('shape', [(300, 300, 5000, 512, 100), (257, 400, 1300, 128, 5), (64, 64, 129, 16, 100),
+                                   # 28 x 28 block tiles of 256 x 256: the materialised path takes k_score_gemm_x3_wide (one
+                                   # wave per SIMD, hand-interleaved k-steps); ragged in rows, items and K (200 -> 224)
+                                   (7000, 400, 7100, 200, 100)])
 def test_presplit_operands_equal_in_loop_split(ops, shape):
     """The score GEMMs fed from the pre-pass that cuts the operands into their bf16 pieces once per call
     (hsk_mf_eval_topk_planes / a hsk_mf_eval_fused_ws_bytes_dim workspace) return the very bits of the form that splits
