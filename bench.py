@@ -575,24 +575,39 @@ def cpu_baseline(headline, budget_s):
             'legs': legs}
 
 
+def child_bench(device, *args):
+    """`python bench.py --cpu-budget 0 <args>` as a child process on the same GPU -> its JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-budget', '0'] + list(args)
+    env = dict(os.environ, MASTER_PORT=os.environ.get('HSK_BENCH_CHILD_PORT', '29541'), RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK=str(device.index or 0))
+    torch.cuda.empty_cache()
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    if p.returncode != 0 or not lines:
+        raise RuntimeError(f'child bench failed (rc {p.returncode}): {p.stderr[-300:]}')
+    return json.loads(lines[-1])
+
+
+def run_cfg5_share_child(device):
+    """one rank's share of configs[4] in a process of its own (190 GB of HBM, and hardware queues of its own: see
+    run_sharded_1rank)"""
+    return child_bench(device, '--workload', 'cfg5', '--steps', '12', '--warmup', '4')['workloads']['cfg5_shard']
+
+
 def run_sharded_1rank(workload, device):
-    import torch.distributed as dist
-    from hassaku_amd.dist import Comm
-    os.environ.setdefault('MASTER_PORT', '29533')
-    os.environ.setdefault('RANK', '0')
-    os.environ.setdefault('WORLD_SIZE', '1')
-    dist.init_process_group('nccl', device_id=device)
-    try:
-        comm = Comm()
-        x = run_training(workload, device, 200, 20, comm=comm)
-        ev = run_eval('lfm2b', device, comm)
-        return {'workload': workload_name(workload, x) + '; ShardedBprMf on a 1-rank RCCL group (hsk_shard_step: the '
-                                                          'whole step from one C call, collectives on the library\'s own communicator)',
-                'value': x['value'], 'unit': 'triplets/s', 'steps': 200, 'warmup': 20, 'ms_per_step': x['ms_per_step'],
-                'fwd_us': x['fwd_us'], 'loss_last_step': x['loss'],
-                'eval_lfm2b_item_sharded_users_per_s': ev['users_per_s']}
-    finally:
-        dist.destroy_process_group()
+    """In a child process of its own: the leg's three streams (step, preparation, exchange) then get hardware queues of
+    their own -- late in THIS process, after the other legs' streams, they end up sharing queues (ROCm maps streams onto
+    a handful of hardware queues in creation order) and the overlap the step is built on is lost: 530 us per step here
+    against 290 in a fresh process, same binary, same box."""
+    x = child_bench(device, '--sharded', '--only', '--steps', '200', '--warmup', '20', '--workload', workload, '--with-eval')
+    return {'workload': x['config']['workload'] + '; ShardedBprMf on a 1-rank RCCL group in a process of its own '
+                                                  '(hsk_shard_step: the whole step from one C call, collectives on the '
+                                                  'library\'s own communicator)',
+            'value': x['value'], 'unit': 'triplets/s', 'steps': x['steps'], 'warmup': x['warmup'],
+            'ms_per_step': x['ms_per_step'], 'fwd_us': x['roofline']['avg_us'],
+            'loss_last_step': x['config']['loss_last_step'],
+            'eval_lfm2b_item_sharded_users_per_s': (x.get('eval') or {}).get('lfm2b', {}).get('users_per_s')}
 
 
 def guarded(fn, *a):
@@ -624,6 +639,7 @@ def main():
     ap.add_argument('--no-pure-gather', action='store_true', help='skip the extra pure-gather timing pass (profiling: keeps the kernel averages of the timed region unmixed)')
     ap.add_argument('--eval-only', default=None, choices=sorted(EVAL_SHAPES), help='only the evaluation leg of this shape (profiling)')
     ap.add_argument('--sharded', action='store_true', help='N=1 through the multi-GPU code path (1-rank process group)')
+    ap.add_argument('--with-eval', action='store_true', help='with --only: the item-sharded lfm2b evaluation leg as well')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -702,6 +718,8 @@ def main():
     if 'stage_us_per_step' in r:
         out['stage_us_per_step'] = r['stage_us_per_step']
 
+    if args.only and args.with_eval and comm is not None:
+        out['eval'] = {'lfm2b': run_eval('lfm2b', device, comm)}
     if not args.only:
         if comm is None:
             # the other BASELINE training configs + the HBM-resident point, each on the same clock as the headline
@@ -718,7 +736,7 @@ def main():
                     'roofline': roofline_of(name, x)}
             out['eval'] = {s: run_eval(s, device) for s in ('ml10m', 'lfm2b')}
             # BASELINE configs[4] needs 8 GPUs; what one GPU can show is one rank's full-size share of it
-            out['workloads']['cfg5_shard'] = guarded(run_cfg5, device, 12, 4)
+            out['workloads']['cfg5_shard'] = guarded(run_cfg5_share_child, device)
             # the multi-GPU code path on this one GPU (a 1-rank RCCL group: every kernel, every collective call and
             # stream hand-off of the sharded step, no link traffic): what the step costs before any xGMI link is involved
             out['sharded_1rank'] = guarded(run_sharded_1rank, args.workload, device)
