@@ -42,7 +42,11 @@ class Trainer:
             raise RuntimeError("hassaku_amd trains on the HIP device only: set `device: cuda` in the conf "
                                "(ROCm PyTorch names the MI355X 'cuda'); there is no CPU trainer")
         hip_ops._lib.require_gpu()
-        self.model = self.pointer_to_model = model.to(self.device)
+        import torch.distributed as tdist
+        multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+        # one process per GPU: the model arrives with its seeded, full tables in HOST memory (as the reference builds
+        # it); only this rank's shards ever go to the device (_build_sharded), so no GPU holds a full table
+        self.model = self.pointer_to_model = model if multi else model.to(self.device)
         self.rec_loss = rec_loss
         self.lr, self.wd = conf['lr'], conf['wd']
         if conf['optimizer'] not in hip_ops.OPT_KINDS:
@@ -57,8 +61,6 @@ class Trainer:
                                              RecSampledSoftmaxLoss)))
         if fusable and isinstance(rec_loss, RecBinaryCrossEntropy) and (model.use_user_bias or model.use_global_bias):
             fusable = False   # bce does send gradient to the user / global bias: autograd path
-        import torch.distributed as tdist
-        multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
         if multi:
             if not (fusable and isinstance(train_loader, TrainDataLoader)
                     and isinstance(rec_loss, RecBayesianPersonalizedRankingLoss)):
@@ -105,11 +107,28 @@ class Trainer:
                                        optimizer=conf['optimizer'], **kw)
 
     def _build_sharded(self, conf):
-        from hassaku_amd.dist import Comm, ShardedBprMf
+        from hassaku_amd.dist import Comm, ShardedBprMf, item_range
         self.comm = Comm()
-        user_emb, item_emb, ib, ub, gb = self.model.tables()
+        W, r = self.comm.world, self.comm.rank
+        dev = torch.device(self.device)
+        user_emb, item_emb, ib, ub, gb = self.model.tables()      # full tables, in host memory (or wherever the model is)
+        U, I = user_emb.shape[0], item_emb.shape[0]
+        # every rank must hold the same initialisation (same seed -> same stream): checked, not assumed
+        chk = torch.tensor([float(user_emb.double().sum()), float(item_emb.double().sum())], dtype=torch.float64, device=dev)
+        lo_chk, hi_chk = chk.clone(), chk.clone()
+        self.comm.all_reduce(lo_chk, op='max')
+        hi_chk.neg_()
+        self.comm.all_reduce(hi_chk, op='max')
+        if not torch.equal(lo_chk, -hi_chk):
+            raise RuntimeError('the ranks were built with different parameter initialisations (different seeds?)')
+        lo, hi = item_range(I, r, W)
+        to_dev = lambda t: t.contiguous().to(dev)                   # noqa: E731  (the shard only)
+        user_emb, item_emb = to_dev(user_emb[r::W]), to_dev(item_emb[lo:hi])
+        ib = None if ib is None else to_dev(ib[lo:hi])
+        ub = None if ub is None else to_dev(ub[r::W])
+        gb = None if gb is None else gb.to(dev)
         loader = self.train_loader
-        arrays = loader.dataset.device_arrays(torch.device(self.device))
+        arrays = loader.dataset.device_arrays(dev)
         # Batch semantics at N > 1.  conf['multi_gpu_batch']:
         #   'per_rank' (default)  every rank contributes train_batch_size positives, a step trains on world x
         #                         train_batch_size of them (weak scaling; lr unchanged -- NOT what the same conf does
@@ -124,8 +143,8 @@ class Trainer:
         sh = ShardedBprMf(self.comm, user_emb, item_emb, ib, ub, gb, lr=self.lr, wd=self.wd,
                           batch=self._rank_batch, n_neg=loader.interaction_sampler.n_neg, seed=loader.seed,
                           loss=self.rec_loss.kind, log_adjust=getattr(self.rec_loss, 'log_adjust', 0.0),
-                          alias=loader.interaction_sampler.alias(torch.device(self.device)),
-                          optimizer=conf['optimizer'], **arrays)
+                          alias=loader.interaction_sampler.alias(dev),
+                          optimizer=conf['optimizer'], inputs_are_shards=True, n_users=U, n_items=I, **arrays)
         self._release_full_tables()
         return sh
 
@@ -152,6 +171,9 @@ class Trainer:
                 'item_bias': None if full_ib is None else full_ib.view(-1, 1)}
         for p, name, _ in self._sharded_params():
             p.data = full[name]
+        m = self.pointer_to_model
+        if m.use_global_bias:                       # replicated, gradient-free under BPR: every rank holds the same value
+            m.global_bias.data = self.sharded.global_bias.detach().clone()
 
     def _save(self):
         if self.sharded is not None:
