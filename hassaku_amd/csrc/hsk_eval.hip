@@ -4,6 +4,7 @@
 // Reference semantics restated: eval/eval.py:237-253 (scores, -inf mask), eval/eval.py:54-99
 // (topk(100), k in {100,50,10,5}), eval/metrics.py:4-105 (precision / recall / ndcg).
 #include "hsk_common.h"
+#include "hsk_gemm_wide.h"
 #include <stdlib.h>
 
 #include <type_traits>
@@ -460,11 +461,6 @@ __global__ __launch_bounds__(256, 2) void k_score_gemm_x3(const float* __restric
 // this load (2.0-2.1 GHz under the looser loop): what bounds it now is power, not issue.
 // Every output element sees the same sequence of MFMAs as in k_score_gemm_x3: the scores are bit-identical.
 // ---------------------------------------------------------------------------------------------
-#define GEMM_W_BM 256
-#define GEMM_W_BN 256
-#define GEMM_W_BK 16
-#define GEMM_W_LDK (GEMM_W_BK + 8)   // 48-byte LDS rows: ds_read_b128 conflict-free
-#define GEMM_W_LDS_BYTES (2 * 3 * (GEMM_W_BM + GEMM_W_BN) * GEMM_W_LDK * 2)
 
 __global__ __launch_bounds__(256, 1) void k_score_gemm_x3_wide(const float* __restrict__ Ib, const float* __restrict__ Ub,
                                                                const float* __restrict__ gb, int n_users, int Dp,
@@ -474,105 +470,31 @@ __global__ __launch_bounds__(256, 1) void k_score_gemm_x3_wide(const float* __re
                                                                const __bf16* __restrict__ Apl,
                                                                const __bf16* __restrict__ Bpl, int a_rows, int b_rows) {
   extern __shared__ __attribute__((aligned(16))) __bf16 wlds[];
-  constexpr int BM = GEMM_W_BM, BN = GEMM_W_BN, LDK = GEMM_W_LDK, TM = 4, TN = 4, WM = 128, WN = 128;
-  constexpr int A_STAGE = 3 * BM * LDK, B_STAGE = 3 * BN * LDK;
+  constexpr int TM = 4, TN = 4, WM = 128, WN = 128;
   __bf16* As = wlds;
-  __bf16* Bs = wlds + 2 * A_STAGE;
+  __bf16* Bs = wlds + 2 * GEMM_W_A_STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * GEMM_W_BM, n0 = blockIdx.x * GEMM_W_BN;
   const int r32 = lane & 31, h = lane >> 5;
-  hsk_f32x16 acc[TM][TN];
+  hsk_w_f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  constexpr int CA = BM * 6 / 256, CB = BN * 6 / 256;   // 16-byte chunks of a tile per thread
-  hsk_vu32x4 ra[CA], rb[CB];
-  int offa[CA], offb[CB];
-#pragma unroll
-  for (int i = 0; i < CA; ++i) {
-    const int c = tid + 256 * i, r = c / 6, j = c - r * 6;
-    offa[i] = (j >> 1) * (BM * LDK) + r * LDK + (j & 1) * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < CB; ++i) {
-    const int c = tid + 256 * i, r = c / 6, j = c - r * 6;
-    offb[i] = (j >> 1) * (BN * LDK) + r * LDK + (j & 1) * 8;
-  }
+  hsk_wide_stage stg;
+  hsk_wide_init(stg, tid);
   const int NT = Dp / GEMM_W_BK;
-  {   // tile 0 -> LDS buffer 0, tile 1 -> registers
-    const __bf16* a = Apl + (long long)m0 * 48;
-    const __bf16* b = Bpl + (long long)n0 * 48;
-#pragma unroll
-    for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const hsk_vu32x4*>(a + (tid + 256 * i) * 8);
-#pragma unroll
-    for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const hsk_vu32x4*>(b + (tid + 256 * i) * 8);
-#pragma unroll
-    for (int i = 0; i < CA; ++i) *reinterpret_cast<hsk_vu32x4*>(As + offa[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < CB; ++i) *reinterpret_cast<hsk_vu32x4*>(Bs + offb[i]) = rb[i];
-    const int t1 = NT > 1 ? 1 : 0;
-    a = Apl + ((long long)t1 * a_rows + m0) * 48;
-    b = Bpl + ((long long)t1 * b_rows + n0) * 48;
-#pragma unroll
-    for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const hsk_vu32x4*>(a + (tid + 256 * i) * 8);
-#pragma unroll
-    for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const hsk_vu32x4*>(b + (tid + 256 * i) * 8);
-  }
+  const __bf16* a0 = Apl + (long long)m0 * 48;
+  const __bf16* b0 = Bpl + (long long)n0 * 48;
+  const long long a_step = (long long)a_rows * 48, b_step = (long long)b_rows * 48;
+  hsk_wide_load(stg, a0, b0, tid);                     // k-tile 0 -> LDS stage 0
+  hsk_wide_store(stg, As, Bs);
+  hsk_wide_load(stg, a0 + (NT > 1 ? a_step : 0), b0 + (NT > 1 ? b_step : 0), tid);   // k-tile 1 -> registers
   __syncthreads();
-  for (int t = 0; t < NT; ++t) {
-    const int buf = t & 1;
-    // (unconditional stores / loads, the tile index clamped: the last steps re-load the last tile and store into a buffer
-    // nobody reads any more -- branches would cut the step into basic blocks)
-    const __bf16* as = As + buf * A_STAGE + (wm * WM + r32) * LDK + 8 * h;
-    const __bf16* bs = Bs + buf * B_STAGE + (wn * WN + r32) * LDK + 8 * h;
-    const int tl = t + 2 < NT ? t + 2 : NT - 1;
-    const __bf16* ga = Apl + ((long long)tl * a_rows + m0) * 48;
-    const __bf16* gbp = Bpl + ((long long)tl * b_rows + n0) * 48;
-    __bf16* sa = As + (buf ^ 1) * A_STAGE;
-    __bf16* sb = Bs + (buf ^ 1) * B_STAGE;
-    hsk_bf16x8 a[3][TM], b[3][TN];
-    auto read_a = [&](int pl) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const hsk_bf16x8*>(as + pl * (BM * LDK) + i * 32 * LDK);
-    };
-    auto read_b = [&](int pl) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[pl][j] = *reinterpret_cast<const hsk_bf16x8*>(bs + pl * (BN * LDK) + j * 32 * LDK);
-    };
-    // the six products of weight >= 2^-16, smallest first: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-    constexpr int PER = TM * TN, NPAIR = CA + CB, CH = 6 * PER / NPAIR;   // 8 MFMAs per (store, load) pair
-    static_assert(6 * PER % NPAIR == 0 && PER % CH == 0, "chunking");
-    read_a(TA[0]);
-    read_b(TB[0]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NPAIR; ++c) {
-#pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        const int m = c * CH + q, tt = m / PER, i = (m % PER) / TN, j = m % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[tt]][i], b[TB[tt]][j], acc[i][j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (c == 0) read_a(TA[1]);             // term 1 needs a[0], b[2]; term 2 a[1], b[1]; terms 3..5 reuse
-      if (c == 1) read_b(TB[1]);
-      if (c == PER / CH) read_a(TA[2]);
-      if (c == PER / CH + 1) read_b(TB[2]);
-      if (c < CA) {
-        *reinterpret_cast<hsk_vu32x4*>(sa + offa[c]) = ra[c];
-        ra[c] = *reinterpret_cast<const hsk_vu32x4*>(ga + (tid + 256 * c) * 8);
-      } else {
-        *reinterpret_cast<hsk_vu32x4*>(sb + offb[c - CA]) = rb[c - CA];
-        rb[c - CA] = *reinterpret_cast<const hsk_vu32x4*>(gbp + (tid + 256 * (c - CA)) * 8);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-  }
+  hsk_wide_kloop(acc, stg, As, Bs, a0, b0, a_step, b_step, NT, tid, wm, wn, r32, h);
   // Epilogue through LDS.  One workgroup per CU: nothing covers this phase, so its length counts in full -- and as
   // dword-per-lane stores (256 per wave, every 128-byte piece split over two cache lines when the row stride is not a
   // multiple of 32 floats: item_count = 10 677) it took about a quarter of the kernel at the ml10m shape.  Per band of
