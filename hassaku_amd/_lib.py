@@ -41,6 +41,7 @@ class HskBprmfState(ctypes.Structure):
         ('catchup_apart', c_int32), ('reserved3', c_int32),
         ('loss_out', c_void_p), ('status', c_void_p),
         ('flush_every', c_int32), ('ws_sharded', c_int32),
+        ('frozen_hyper', c_double * 5), ('frozen_opt', c_int32), ('frozen_valid', c_int32),
     ]
 
 

@@ -261,10 +261,21 @@ static int hsk_check_state(const hsk_bprmf_state* st) {
               st->opt_kind);
   HSK_REQUIRE((st->alias_prob == nullptr) == (st->alias_idx == nullptr), HSK_ERR_INVALID,
               "alias table needs both alias_prob and alias_idx");
+  // the device table of per-step Adam scalars (lazy replay, replayed graphs) was computed from these at init time
+  if (st->frozen_valid) {
+    const double now[5] = {st->lr, st->beta1, st->beta2, st->eps, st->wd};
+    HSK_REQUIRE(memcmp(now, st->frozen_hyper, sizeof(now)) == 0 && st->opt_kind == st->frozen_opt, HSK_ERR_INVALID,
+                "lr / betas / eps / wd / optimizer changed after hsk_bprmf_init_workspace: flush, then call "
+                "hsk_bprmf_init_workspace again with the new values");
+  }
   return HSK_OK;
 }
 
-extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t stream_) {
+static void hsk_aux_drop_graphs(void* aux);   // (defined with struct hsk_aux below)
+
+extern "C" int hsk_bprmf_init_workspace(hsk_bprmf_state* st, hsk_stream_t stream_) {
+  HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
+  st->frozen_valid = 0;
   int rc = hsk_check_state(st);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -302,6 +313,11 @@ extern "C" int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t 
   }
   HSK_HIP(hipMemcpyAsync(w.adam_tab, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice, stream));
   HSK_HIP(hipStreamSynchronize(stream));
+  const double now[5] = {st->lr, st->beta1, st->beta2, st->eps, st->wd};
+  memcpy(st->frozen_hyper, now, sizeof(now));
+  st->frozen_opt = st->opt_kind;
+  st->frozen_valid = 1;
+  hsk_aux_drop_graphs(st->aux);   // graphs captured for the previous hyper-parameters are stale
   return HSK_OK;
 }
 
@@ -412,6 +428,13 @@ struct hsk_aux {
   bool graph_broken = false;   // a capture failed once: stay with eager launches
   int64_t graph_launches = 0;  // replayed runs so far (hsk_bprmf_graph_replays)
 };
+
+static void hsk_aux_drop_graphs(void* a_) {
+  hsk_aux* a = (hsk_aux*)a_;
+  if (!a) return;
+  for (auto& g : a->graphs) (void)hipGraphExecDestroy(g.exec);
+  a->graphs.clear();
+}
 
 extern "C" void hsk_aux_destroy(void* a_) {
   hsk_aux* a = (hsk_aux*)a_;

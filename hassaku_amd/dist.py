@@ -379,9 +379,17 @@ class ShardedBprMf:
             comm.broadcast(idd, src=0)
             raw = bytes(idd.cpu().tolist())
             rt = self.lib.hsk_shard_rt_create(W, r, ctypes.c_char_p(raw))
-            if not rt:
-                raise RuntimeError('hsk_shard_rt_create failed: ' + self.lib.hsk_last_error().decode('utf-8', 'replace'))
-            self._rt = ctypes.c_void_p(rt)
+            # every rank takes the native path or none does (a rank on its own in the phased path would wait for ever)
+            ok = torch.tensor([1.0 if rt else 0.0], device=dev)
+            comm.all_reduce(ok)
+            if int(ok.item()) == W:
+                self._rt = ctypes.c_void_p(rt)
+            else:
+                import warnings
+                warnings.warn('hsk_shard_rt_create failed on a rank (' + self.lib.hsk_last_error().decode('utf-8', 'replace')
+                              + '): the sharded step falls back to the phase-by-phase path')
+                if rt:
+                    self.lib.hsk_shard_rt_destroy(ctypes.c_void_p(rt))
 
     @property
     def step_count(self) -> int:

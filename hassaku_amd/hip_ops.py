@@ -555,6 +555,21 @@ class BprMfFusedState:
     def flush(self):
         _lib.check(self.lib.hsk_bprmf_flush(ctypes.byref(self.st), _stream()), 'hsk_bprmf_flush')
 
+    def set_hyper(self, lr=None, wd=None, beta1=None, beta2=None, eps=None):
+        """Change the optimiser's hyper-parameters between steps (an LR schedule).  The library freezes them when the
+        workspace is prepared -- the per-step Adam scalars of the lazy replay and of replayed graphs are a device table
+        -- and refuses a step that finds them changed; this brings every row up to date under the OLD values (dense
+        semantics: a pending zero-gradient step belongs to the schedule that was in force when it was due), installs the
+        new ones and prepares the workspace again.  Loss sums and the step counter carry over."""
+        self.flush()
+        self.check_status()
+        loss_sum = self.loss_out.clone()
+        for name, val in (('lr', lr), ('wd', wd), ('beta1', beta1), ('beta2', beta2), ('eps', eps)):
+            if val is not None:
+                setattr(self.st, name, float(val))
+        _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(self.st), _stream()), 'hsk_bprmf_init_workspace')
+        self.loss_out.copy_(loss_sum)
+
     def last_loss(self) -> float:
         return float(self.loss_out[0].item())
 

@@ -245,6 +245,13 @@ typedef struct hsk_bprmf_state {
      its exchange buffers: the [max_batch, dim] row buffers of the single-GPU step are not allocated.  The size is then
      hsk_shard_base_workspace_bytes(); the single-GPU entry points refuse such a state */
   int32_t ws_sharded;
+  /* library scratch, written by hsk_bprmf_init_workspace: the hyper-parameters the workspace was prepared for (the
+     per-step Adam scalars of the lazy replay and of replayed graphs live in a device table computed from them).
+     lr / beta1 / beta2 / eps / wd / opt_kind are FROZEN from then on: a call that finds them changed fails with
+     HSK_ERR_INVALID instead of mixing two schedules -- flush, set the new values, call hsk_bprmf_init_workspace again */
+  double frozen_hyper[5];
+  int32_t frozen_opt;
+  int32_t frozen_valid;
 } hsk_bprmf_state;
 
 int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim,
@@ -256,7 +263,8 @@ int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim,
  * cfg5 shard: ~210), never (2^30: only an explicit flush sweeps) when a row is touched every few steps anyway
  * (ml10m: a user is in every 17th batch). */
 int32_t hsk_bprmf_flush_cadence(const hsk_bprmf_state* st, int32_t table, int64_t touched_rows);
-int hsk_bprmf_init_workspace(const hsk_bprmf_state* st, hsk_stream_t stream);
+/* prepares the workspace for st's shapes and hyper-parameters (synchronous); st->step rows are taken as current */
+int hsk_bprmf_init_workspace(hsk_bprmf_state* st, hsk_stream_t stream);
 
 /* One step on a loader-provided batch (u_idx [batch], i_idx [batch, n_cols], column 0 positive):
  * forward + BPR loss + backward + AdamW on every parameter, results equal to the reference's

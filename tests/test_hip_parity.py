@@ -991,10 +991,12 @@ def test_eval_cfg4_shape_eight_item_shards_vs_float64(ops):
     assert torch.equal(mi.long()[clear], ri[:, :k][clear])
 
 
-def test_replayed_graph_is_recaptured_when_the_state_changes(ops):
-    """A captured run has lr / wd / pointers frozen into its kernel arguments: changing st.lr between two
-    steps_sampled() calls (an LR schedule) must give what the eager path gives, bit for bit -- i.e. a fresh capture,
-    never a replay of the stale graph."""
+def test_hyper_parameters_are_frozen_and_set_hyper_re_prepares(ops):
+    """lr / wd / betas / eps live in a device table of per-step Adam scalars (lazy replay, replayed graphs) computed when
+    the workspace is prepared: a step that finds st.lr changed FAILS (it would otherwise mix two schedules, or replay a
+    graph with the old value frozen into it); set_hyper() -- flush under the old values, new values, workspace prepared
+    again, captured graphs dropped -- is the way, and a run issued as replayed graphs then equals the same steps issued
+    one by one, bit for bit, across three LR changes."""
     n_users, n_items, D, B, N = 300, 900, 64, 128, 6
     rng = np.random.RandomState(4)
     pairs = np.argwhere(rng.rand(n_users, n_items) < 0.15)
@@ -1009,8 +1011,9 @@ def test_replayed_graph_is_recaptured_when_the_state_changes(ops):
         st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
                              coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
         st.st.nnz = order.numel()
-        for run, lr in enumerate((1e-3, 5e-2, 1e-3)):          # back to the first value: that graph may be cached
-            st.st.lr = lr
+        for run, lr in enumerate((1e-3, 5e-2, 1e-3)):          # back to the first value: no stale graph may survive
+            if run:
+                st.set_hyper(lr=lr)
             if chunked:
                 st.steps_sampled(order, run * 64 * B, 64, B, N)
             else:
@@ -1018,10 +1021,17 @@ def test_replayed_graph_is_recaptured_when_the_state_changes(ops):
                     st.step_sampled(order, (run * 64 + s) * B, B, N)
         st.flush()
         st.check_status()
-        assert st.graph_replays() == (3 if chunked else 0)
-        res.append({k: v.cpu().numpy().copy() for k, v in t.items()})
-    for k in res[0]:
-        assert np.array_equal(res[0][k], res[1][k]), k
+        assert st.graph_replays() == (3 if chunked else 0) and st.step_count == 192
+        res.append(({k: v.cpu().numpy().copy() for k, v in t.items()}, st.pop_loss_sum()))
+    assert res[0][1] == res[1][1]
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    # the raw field changed behind the library's back: refused, not obeyed
+    st.st.lr = 0.5
+    with pytest.raises(RuntimeError, match='init_workspace'):
+        st.step_sampled(order, 0, B, N)
+    st.st.lr = 1e-3
+    st.step_sampled(order, 0, B, N)
 
 
 def test_score_all_fast_path_is_not_keyed_on_the_address():

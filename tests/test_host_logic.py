@@ -45,7 +45,7 @@ def _header_fields(struct_name):
             if not decl:
                 continue
         for part in decl.split(','):
-            m = re.search(r'([A-Za-z_][A-Za-z0-9_]*)\s*$', part.strip())
+            m = re.search(r'([A-Za-z_][A-Za-z0-9_]*)\s*$', re.sub(r'\[[^\]]*\]\s*$', '', part.strip()))   # name, or name[n]
             if m:
                 names.append(m.group(1))
     return names
