@@ -587,7 +587,8 @@ class BprMfFusedState:
 # evaluation
 # ------------------------------------------------------------------------------------------------
 FUSED_TOPK_MAX_K = 128     # hsk_mf_eval_topk_fused (HSK_SEL_KMAX)
-FUSED_TOPK_MIN_ITEMS = 32768   # below this many columns the warm-up of the in-GEMM selection (every row starts from
+FUSED_TOPK_MIN_ITEMS = 36864   # (round 3, with the 256 x 256 score GEMM: materialised / fused M users/s at U = 16 384 --
+                               # 32 768 items 2.99 / 2.84, 40 960: 2.33 / 2.41)  below this many columns the warm-up of the in-GEMM selection (every row starts from
                                # an empty list in every item split) costs more than writing the scores out: measured
                                # 4.3 M users/s fused against 5.6 M materialised at 10 677 items, 0.62 M against 0.52 M
                                # at 131 072
