@@ -89,6 +89,7 @@ struct hsk_ws {
   int *stamp, *stamp_b;    // per buffer set: stamp[u] = step the set's batch is trained on (for its users)
   int* claim;              // ahead-of-time catch-up: last step at which a row was claimed
   int *touched, *n_touched, *touched_b, *n_touched_b;   // per buffer set: items with entries (compact), their count
+  int* pend;               // lazy item AdamW: per entry of the step's touched list, the step its moments stand at
   // item-partitioned forward: dUb holds n_part_max partial rows per batch position, loss_b as many planes; the batch rows
   // have n_part - 1 extra columns
   int n_part_max;
@@ -180,6 +181,7 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.touched_b = (int*)take(ent * 4);
   w.n_touched = (int*)take(256);
   w.n_touched_b = (int*)take(256);
+  w.pend = (int*)take(ent * 4);
   w.u32_b = (int*)take(G * max_batch * 4);
   w.it32_b = (int*)take(G * ent * 4);
   w.perm1_b = (int2*)take(ent * 8);
@@ -645,7 +647,7 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
   const unsigned groups = (unsigned)hsk_align_up(hsk_ceil_div(n_list, 4 * ipw), 8);
   const hsk_item_args ia = {Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias,
                             st->v_item_bias, urow_index, w.g_s, w.perm, w.offsets, I, K, D, n_slices_pad, ipw, c,
-                            gI_out, gIb_out, w.touched, w.n_touched, w.last_step_i, (int)st->step,
+                            gI_out, gIb_out, w.touched, w.n_touched, w.last_step_i, (int)st->step, w.pend,
                             ua ? ua->desc : nullptr, ua ? ua->rel : 0, w.adam_tab, HSK_ADAM_TAB_LEN, n_part};
   const bool gen = APPLY && st->opt_kind != HSK_OPT_ADAMW;   // APPLY == false never calls the update
   const unsigned nblk = groups * (whole_rows ? 1 : n_slices_pad);
@@ -875,12 +877,12 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       HSK_STAGE(HSK_STAGE_ITEM, (k_item_catch_up<2, true><<<nblk, 256, 0, stream>>>(
                                     st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias, st->m_item_bias,
                                     st->v_item_bias, w.touched, w.n_touched, w.last_step_i, D, (int)st->step, c,
-                                    w.adam_tab, HSK_ADAM_TAB_LEN, aux ? aux->g_desc : nullptr, aux ? aux->g_rel : 0)));
+                                    w.adam_tab, HSK_ADAM_TAB_LEN, aux ? aux->g_desc : nullptr, aux ? aux->g_rel : 0, w.pend)));
     else
       HSK_STAGE(HSK_STAGE_ITEM, (k_item_catch_up<2, false><<<nblk, 256, 0, stream>>>(
                                     st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias, st->m_item_bias,
                                     st->v_item_bias, w.touched, w.n_touched, w.last_step_i, D, (int)st->step, c,
-                                    w.adam_tab, HSK_ADAM_TAB_LEN, aux ? aux->g_desc : nullptr, aux ? aux->g_rel : 0)));
+                                    w.adam_tab, HSK_ADAM_TAB_LEN, aux ? aux->g_desc : nullptr, aux ? aux->g_rel : 0, w.pend)));
     HSK_LAUNCH_CHECK();
   }
   if (hsk_pf_early(B)) {

@@ -47,6 +47,7 @@ struct hsk_item_args {
   hsk_adamw_consts c;
   float* gI_out; float* gIb_out;
   const int* touched; const int* n_touched; int* last_step_i; int step;   // LAZY only
+  const int* pend;        // LAZY: per list entry, the step the row's MOMENTS stand at (k_item_catch_up wrote p only)
   const hsk_step_desc* desc; int rel;   // graph replay: step = desc->step0 + rel + 1, c from ctab
   const float2* ctab; int ctab_len;
   int n_part;             // PART kernels (item-partitioned forward): d loss/d s_0 of a positive = g_s[e] + .. + g_s[e + n_part-1]
@@ -148,6 +149,16 @@ __device__ __forceinline__ void hsk_item_sliced_body(const hsk_item_args& a, int
       }
     }
     if (APPLY) {
+      // lazy rows: the moments still stand at step pend[idx] (the catch-up wrote the parameter only): the missed
+      // zero-gradient steps' m <- m + w1 (-m), v <- beta2 v, the replay's own operations
+      const int behind = (LAZY && !GEN && a.pend) ? (step - 1) - hsk_uniform_i(a.pend[idx]) : 0;
+      for (int r = 0; r < behind; ++r) {
+#pragma unroll
+        for (int q = 0; q < VS; ++q) {
+          m.v[q] = fmaf(c.w1, -m.v[q], m.v[q]);
+          v.v[q] = v.v[q] * c.beta2;
+        }
+      }
       if (live) {
 #pragma unroll
         for (int q = 0; q < VS; ++q) hsk_adamw_update<GEN>(p.v[q], m.v[q], v.v[q], acc.v[q], c);
@@ -159,6 +170,10 @@ __device__ __forceinline__ void hsk_item_sliced_body(const hsk_item_args& a, int
         const float gbias = hsk_wave_sum(gb_lane);
         if (lane == 0) {
           float pb = Ib[i], mb = mIb[i], vb = vIb[i];
+          for (int r = 0; r < behind; ++r) {
+            mb = fmaf(c.w1, -mb, mb);
+            vb = vb * c.beta2;
+          }
           hsk_adamw_update<GEN>(pb, mb, vb, gbias, c);
           Ib[i] = pb;
           mIb[i] = mb;
@@ -228,6 +243,18 @@ __device__ __forceinline__ void hsk_item_row_body(const hsk_item_args& a, int bi
       for (int r = 0; r < 4; ++r)
         if (j + r < nr) hsk_row_axpy(acc, hsk_readlane_f(myg, j + r), buf[r]);
     }
+  }
+  const int behind = (LAZY && !GEN && a.pend) ? (step - 1) - hsk_uniform_i(a.pend[idx]) : 0;   // see hsk_item_sliced_body
+  for (int r = 0; r < behind; ++r) {
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        m.c[cc].v[q] = fmaf(c.w1, -m.c[cc].v[q], m.c[cc].v[q]);
+        v.c[cc].v[q] = v.c[cc].v[q] * c.beta2;
+      }
+    mb = fmaf(c.w1, -mb, mb);
+    vb = vb * c.beta2;
   }
 #pragma unroll
   for (int cc = 0; cc < NCH; ++cc)

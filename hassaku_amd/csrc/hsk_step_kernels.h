@@ -492,7 +492,9 @@ __global__ __launch_bounds__(256) void k_user_update(float* __restrict__ Uw, flo
 // Zero-gradient replay of one user row by a whole 256-thread workgroup (thread t owns VV consecutive elements per
 // pass): the replay is a serial chain of `to - from` dependent updates per element, so a row is spread over as
 // many lanes as it has elements instead of being held by one wave.
-template <int VV, bool GEN>
+// P_ONLY: only the parameter leaves (the moments stay as of step `from`: whoever rewrites the row next replays them --
+// two multiplications per element and step, no table -- see k_item_catch_up)
+template <int VV, bool GEN, bool P_ONLY = false>
 __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, float* __restrict__ mrow,
                                                   float* __restrict__ vrow, int D, int from, int to,
                                                   const hsk_adamw_consts& base, const float2* __restrict__ tab,
@@ -521,13 +523,15 @@ __device__ __forceinline__ void hsk_row_replay_wg(float* __restrict__ prow, floa
 #else
       hsk_stg<VV>(prow + d0, p);
 #endif
+      if (!P_ONLY) {
 #if HSK_REPLAY_NT
-      hsk_stg_nt<VV>(mrow + d0, m);
-      hsk_stg_nt<VV>(vrow + d0, v);
+        hsk_stg_nt<VV>(mrow + d0, m);
+        hsk_stg_nt<VV>(vrow + d0, v);
 #else
-      hsk_stg<VV>(mrow + d0, m);
-      hsk_stg<VV>(vrow + d0, v);
+        hsk_stg<VV>(mrow + d0, m);
+        hsk_stg<VV>(vrow + d0, v);
 #endif
+      }
     }
   }
 }
@@ -602,6 +606,10 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
 // Lazy ITEM AdamW (catalogues far larger than a batch touches): the items of this batch -- the compact list the item
 // sort leaves in `touched` -- are brought up to step-1 before the forward reads them; every other item row keeps its
 // zero-gradient steps for later, exactly like the user rows above.  One workgroup per listed item.
+// The forward needs the PARAMETER row only, and the item pass of this same step rewrites (p, m, v) of exactly these rows
+// anyway: under AdamW (!GEN; with L2 decay the moments depend on p's path) only p is written here -- 2 of the 6 KB per
+// row at D = 512 -- and pend[j] tells the item pass from which step the moments of list entry j are to be brought
+// forward (m <- m + w1 (-m), v <- beta2 v per missed step: the replay's own operations, so the bits are the dense ones).
 template <int VV, bool GEN>
 __global__ __launch_bounds__(256) void k_item_catch_up(float* __restrict__ Iw, float* __restrict__ mI,
                                                        float* __restrict__ vI, float* __restrict__ Ib,
@@ -610,24 +618,34 @@ __global__ __launch_bounds__(256) void k_item_catch_up(float* __restrict__ Iw, f
                                                        const int* __restrict__ n_touched, int* __restrict__ last_step_i,
                                                        int D, int step, hsk_adamw_consts c,
                                                        const float2* __restrict__ tab, int tab_len,
-                                                       const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0) {
+                                                       const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0,
+                                                       int* __restrict__ pend = nullptr) {
   if (desc) step = desc->step0 + rel + 1;   // graph replay (c's per-step fields are rebuilt per replayed step below)
   if ((int)blockIdx.x >= *n_touched) return;
   const int row = touched[blockIdx.x];
   const int done = last_step_i[row];
+  constexpr bool P_ONLY = !GEN;
+  const bool p_only = P_ONLY && pend != nullptr;
+  if (pend && threadIdx.x == 0) pend[blockIdx.x] = p_only ? min(done, step - 1) : step - 1;
   if (done >= step - 1) return;
-  hsk_row_replay_wg<VV, GEN>(Iw + (long long)row * D, mI + (long long)row * D, vI + (long long)row * D, D, done, step - 1,
-                             c, tab, tab_len);
+  if (p_only)
+    hsk_row_replay_wg<VV, GEN, P_ONLY>(Iw + (long long)row * D, mI + (long long)row * D, vI + (long long)row * D, D, done,
+                                       step - 1, c, tab, tab_len);
+  else
+    hsk_row_replay_wg<VV, GEN>(Iw + (long long)row * D, mI + (long long)row * D, vI + (long long)row * D, D, done,
+                               step - 1, c, tab, tab_len);
   __syncthreads();  // every thread has read last_step_i[row]
   if (threadIdx.x == 0) {
     if (Ib) {
       float pb = Ib[row], mb = mIb[row], vb = vIb[row];
       for (int t = done + 1; t <= step - 1; ++t) hsk_adamw_update<GEN>(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
       Ib[row] = pb;
-      mIb[row] = mb;
-      vIb[row] = vb;
+      if (!p_only) {
+        mIb[row] = mb;
+        vIb[row] = vb;
+      }
     }
-    last_step_i[row] = step - 1;
+    last_step_i[row] = step - 1;   // (of p; with pend set, of the moments as recorded there)
   }
 }
 

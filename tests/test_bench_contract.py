@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,3 +41,22 @@ def test_bench_prints_one_contract_line():
     # configs[0], 20 warm-up + 200 timed steps, with 0 and with 4 loader workers
     assert [leg['train_n_workers'] for leg in c['legs']] == [0, 4]
     assert all(leg['steps'] >= 200 and leg['warmup'] == 20 and leg['value'] > 0 for leg in c['legs'])
+
+
+@pytest.mark.gpu
+def test_cfg5_share_leg_runs_at_a_scaled_shape(monkeypatch):
+    """bench.run_cfg5 (the `workloads.cfg5_shard` leg: rank 3 of 8 of BASELINE configs[4] on its own, collectives stubbed by
+    dist.LoopbackComm) on tables scaled down 500 x: the leg's code path, keys and bookkeeping -- so that a regression shows
+    here and not as an `error` entry in the driver's bench line."""
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    monkeypatch.setitem(bench.CFG5, 'U', 200_000)
+    monkeypatch.setitem(bench.CFG5, 'I', 80_000)
+    monkeypatch.setitem(bench.CFG5, 'B', 64)
+    x = bench.run_cfg5(torch.device('cuda', 0), 3, 2)
+    assert x['ranks_running'] == 1 and x['n_gpus_of_the_job'] == 8 and x['ms_per_step'] > 0
+    assert x['roofline']['bound'] == 'hbm' and x['roofline']['launches'] == 3 and x['roofline']['achieved'] > 0
+    assert set(x['stage_us_per_step']) == {'fwd', 'item', 'user'}
+    assert x['roofline']['kept_entries_per_step'] > 64 * 8 * 200 // 16       # about an eighth of the global batch's entries
+    assert x['lazy_sweep']['sweep_ms'] > 0 and x['value_rank_share'] > 0 and np.isfinite(x['loss_last_step_local_share'])
