@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void k_presplit16(const float* __restrict__ X,
   *reinterpret_cast<bf16x4*>(dst + 32) = p3;
 }
 
-template <int BM, int BN, int WM, int WN, bool PROF = false>   // block tile, per-wave tile; (BM / WM) * (BN / WN) == 4 waves; PROF: diagnostic stamps
-__global__ __launch_bounds__(256, 1) void k_gemm_v4(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp,
+template <int BM, int BN, int WM, int WN, bool PROF = false, int OCC = 1>   // block tile, per-wave tile; (BM / WM) * (BN / WN) == 4 waves; PROF: diagnostic stamps
+__global__ __launch_bounds__(256, OCC) void k_gemm_v4(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp,
                                                      float* __restrict__ C, int m_rows, int n_rows,
                                                      unsigned long long* __restrict__ stamps_ = nullptr) {
   unsigned long long* stamps = PROF ? stamps_ : nullptr;
@@ -147,10 +147,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_v4(const __bf16* __restrict__ A
       }
       __builtin_amdgcn_sched_barrier(0);
       // fragments of the following terms: term 1 needs a[0], b[2]; term 2 needs a[1], b[1] (terms 3..5 reuse)
-      if (c == 0) read_a(TA[1]);
-      if (c == 1) read_b(TB[1]);
-      if (c == PER / CH) read_a(TA[2]);
-      if (c == PER / CH + 1) read_b(TB[2]);
+      {   // term k (k = 1, 2) starts at chunk k * PER / CH: its fragments are read behind the one or two chunks in front
+        constexpr int S1 = PER / CH, S2 = 2 * PER / CH;
+        if (c == (S1 >= 2 ? S1 - 2 : S1 - 1)) read_a(TA[1]);
+        if (c == S1 - 1) read_b(TB[1]);
+        if (c == (S1 >= 2 ? S2 - 2 : S2 - 1)) read_a(TA[2]);
+        if (c == S2 - 1) read_b(TB[2]);
+      }
       if (c < CA) {
         *reinterpret_cast<u32x4*>(sa + offa[c]) = ra[c];
         ra[c] = *reinterpret_cast<const u32x4*>(ga + (tid + 256 * c) * 8);
@@ -183,16 +186,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_v4(const __bf16* __restrict__ A
       }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int OCC = 1>
 static void run(const char* name, const __bf16* Ap, const __bf16* Bp, float* C, const float* Cref_dev) {
   const size_t lds = (size_t)2 * 3 * (BM + BN) * LDK * 2;
-  CK(hipFuncSetAttribute((const void*)k_gemm_v4<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)k_gemm_v4<BM, BN, WM, WN, false, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   dim3 grid(N / BN, M / BM);
   float tot = 0, best = 1e9;
   for (int rep = 0; rep < 22; ++rep) {
     CK(hipEventRecord(e0));
-    k_gemm_v4<BM, BN, WM, WN><<<grid, 256, lds>>>(Ap, Bp, C, M, N);
+    k_gemm_v4<BM, BN, WM, WN, false, OCC><<<grid, 256, lds>>>(Ap, Bp, C, M, N);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (rep >= 2) { tot += ms; best = fminf(best, ms); }
@@ -208,8 +211,8 @@ static void run(const char* name, const __bf16* Ap, const __bf16* Bp, float* C, 
   {   // diagnostic launches: the clock the chip holds inside the loop, and the loop's cycles per MFMA
     const int n_wg = (N / BN) * (M / BM);
     unsigned long long* st; CK(hipMalloc(&st, (size_t)n_wg * 64));
-    CK(hipFuncSetAttribute((const void*)k_gemm_v4<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int rep = 0; rep < 30; ++rep) k_gemm_v4<BM, BN, WM, WN, true><<<grid, 256, lds>>>(Ap, Bp, C, M, N, st);
+    CK(hipFuncSetAttribute((const void*)k_gemm_v4<BM, BN, WM, WN, true, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int rep = 0; rep < 30; ++rep) k_gemm_v4<BM, BN, WM, WN, true, OCC><<<grid, 256, lds>>>(Ap, Bp, C, M, N, st);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> hs((size_t)n_wg * 8);
     CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
@@ -325,6 +328,7 @@ int main() {
     printf("%-28s mean %.1f us = %.1f TFLOP/s fp32-equivalent\n", "128x128 (2 WG/CU) baseline", tot / 20 * 1e3, 2.0 * M * N * K / (tot / 20 * 1e-3) / 1e12);
   }
   run<256, 256, 128, 128>("256x256, waves of 128x128", Ap, Bp, C, Cref);
+  run<128, 128, 64, 64, 2>("128x128 interleaved, 2 WG/CU", Ap, Bp, C, Cref);
   std::vector<float> hC((size_t)256 * N);
   CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
   double maxabs = 0, scale = 0;
