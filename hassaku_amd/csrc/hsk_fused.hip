@@ -1675,3 +1675,15 @@ extern "C" int hsk_embedding_backward(const float* grad_out, const int64_t* idx,
   HSK_LAUNCH_CHECK();
   return HSK_OK;
 }
+
+#ifdef HSK_DEBUG_XCC
+// debugging builds only (make EXTRA=-DHSK_DEBUG_XCC): [workgroup label][XCC id] counts of k_item_user's item workgroups
+extern "C" int hsk_debug_xcc(unsigned* out64, int reset) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(hsk_dbg_xcc), 64 * sizeof(unsigned)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hsk_dbg_xcc), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

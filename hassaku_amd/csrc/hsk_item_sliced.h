@@ -38,6 +38,9 @@ __device__ __forceinline__ void hsk_stg_stream(float* p, const hsk_vec<VS>& x) {
 #endif
 }
 
+#ifdef HSK_DEBUG_XCC
+__device__ unsigned hsk_dbg_xcc[64];   // [workgroup label (index % 8)][XCC id] of the item workgroups, debugging builds only
+#endif
 struct hsk_item_args {
   const float* Uw;        // user rows: the table (+ u32), an exchange buffer (+ slot index) or ucur (u32 == NULL)
   float* Iw; float* Ib; float* mI; float* vI; float* mIb; float* vIb;
@@ -312,6 +315,13 @@ void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int
     hsk_user_ahead_body<V, NCH, FULL, GEN>(aa, bid - n_user_blocks);
     return;
   }
+#ifdef HSK_DEBUG_XCC
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    atomicAdd(&hsk_dbg_xcc[((bid - n_user_blocks) & 7) * 8 + (xcc & 7)], 1u);
+  }
+#endif
   hsk_item_sliced_body<true, VS, GEN, LAZYI, PART>(ia, bid - n_user_blocks - (LAZYI ? n_ahead_blocks : 0));
 }
 
