@@ -462,7 +462,7 @@ def run_eval(shape, device, comm=None, chunk=None, repeat=3):
     from hassaku_amd.eval.eval import FullEvaluator
     U, I, D, npos = EVAL_SHAPES[shape]
     if chunk is None:     # (wide catalogue: top-k inside the GEMM; narrow: materialised scores, 0.7 GB of them per chunk at ml10m)
-        chunk = 16384
+        chunk = int(os.environ.get('HSK_BENCH_EVAL_CHUNK', '16384'))
     user_emb, item_emb, item_bias, ds = eval_problem(shape, device)
     ev = FullEvaluator(aggr_by_group=True, n_groups=0, user_to_user_group=None)
     ks = sorted(ev.K_VALUES, reverse=True)

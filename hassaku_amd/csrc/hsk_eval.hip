@@ -621,6 +621,15 @@ __device__ void hsk_bitonic_desc(unsigned long long* s, int n) {
 // wave 0 -- lane l owns bins 4l .. 4l+3, a suffix sum over the lanes -- instead of one thread walking 256 dependent LDS
 // reads (7 us per walk, and a selection makes several).  No such bin (fewer than `need` keys in bins 1..255): bin 0.
 // Every lane of wave 0 returns the same (bin, keys above it, keys in it); other waves must not call.
+__device__ __forceinline__ int hsk_topk_wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
 struct hsk_bin_pick { unsigned int bin, above, count; };
 __device__ __forceinline__ hsk_bin_pick hsk_pick_bin_256(const unsigned int* h, unsigned int need, int lane) {
   const unsigned int c0 = h[lane * 4], c1 = h[lane * 4 + 1], c2 = h[lane * 4 + 2], c3 = h[lane * 4 + 3];
@@ -662,10 +671,13 @@ __device__ __forceinline__ void hsk_topk_rows_body(const float* __restrict__ X, 
                                                    long long idx_offset, float* __restrict__ out_vals,
                                                    IdxOut* __restrict__ out_idx) {
   __shared__ unsigned int hist[256];
+  // the 12-bit histogram is dead (summed into part12, its b1 bin's count copied out) before the first candidate is
+  // written: one 16 KB array serves both, and twice as many rows are in flight per CU
   __shared__ unsigned long long cand[TOPK_CAND_MAX];
+  static_assert(sizeof(unsigned long long) * TOPK_CAND_MAX >= sizeof(unsigned int) * 4096, "hist12 lives in cand");
+  unsigned int* const hist12 = reinterpret_cast<unsigned int*>(cand);
   __shared__ unsigned int sh_prefix, sh_need, sh_ngt, sh_neq, sh_taken;
-  __shared__ unsigned int wave_cnt[4];
-  __shared__ unsigned int hist12[4096];
+  __shared__ unsigned int wave_cnt[4], wave_tot[4];
   __shared__ unsigned int part12[256];
 
   const int tid = threadIdx.x;
@@ -688,27 +700,84 @@ __device__ __forceinline__ void hsk_topk_rows_body(const float* __restrict__ X, 
   const bool in_regs = cols + shift <= 256 * TOPK_RPT;
   auto col_of = [&](int i) { return 4 * (tid + 256 * (i >> 2)) + (i & 3) - shift; };
   uint32_t kreg[TOPK_RPT];
+  // k <= 256 on a row held in registers: NO histogram at all.  Every thread takes the maximum of its keys; every wave
+  // the ceil(k/4)-th largest of its 64 maxima (ranked by counting over readlane broadcasts, no LDS); L = the smallest
+  // of the four.  At least 4 * ceil(k/4) >= k distinct elements are >= L, so L is a lower bound of the row's k-th
+  // largest key, and on scores without structure along the columns only k .. ~1.5 k keys are >= L: they are ranked
+  // below by counting.  (The 12-bit histogram this replaces cost 48 LDS atomics per thread plus its 8-bit refinements.)
+  // Keys of columns outside the row are 0 here (below every key a float maps to, NaNs with a set sign bit aside).
+#ifndef HSK_TOPK_MAXIMA
+#define HSK_TOPK_MAXIMA 1     // 0: the histogram selection for every k (comparison builds)
+#endif
+  const bool by_maxima = HSK_TOPK_MAXIMA && in_regs && k <= 256;
+  unsigned int my_off = 0, mx_b1 = 0, mx_cand = 0;   // by_maxima: first candidate slot of this thread, L, candidates
   if (cols >= 4096) {
-    for (int c = tid; c < 4096; c += 256) hist12[c] = 0;
+    if (!by_maxima)
+      for (int c = tid; c < 4096; c += 256) hist12[c] = 0;
     if (in_regs) {
 #pragma unroll
       for (int v = 0; v < TOPK_RPT / 4; ++v) {
+        // No branch around a load: TOPK_RPT / 4 independent 16-byte loads, all in flight together (with a scalar path
+        // for the pieces that straddle the row's ends every piece waited for the one before it: 12-16 memory round
+        // trips per row, ~20 us, where the row's bytes need 2).  A piece that straddles an end is still ONE aligned
+        // 16-byte load: it holds at least one element of the row, so it lies inside that element's page; what it
+        // brings along from outside the row is never looked at (every use below tests the column).  Pieces wholly
+        // outside re-read the row's first piece.
         const int c0 = col_of(4 * v);
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 >= 0 && c0 + 3 < cols) {
-          x = *reinterpret_cast<const float4*>(row + c0);          // 16-byte aligned by construction
-        } else {                                                   // the pieces that straddle the row's ends
-          if (c0 + 0 >= 0 && c0 + 0 < cols) x.x = row[c0 + 0];
-          if (c0 + 1 >= 0 && c0 + 1 < cols) x.y = row[c0 + 1];
-          if (c0 + 2 >= 0 && c0 + 2 < cols) x.z = row[c0 + 2];
-          if (c0 + 3 >= 0 && c0 + 3 < cols) x.w = row[c0 + 3];
-        }
-        kreg[4 * v + 0] = hsk_f2key(x.x);
-        kreg[4 * v + 1] = hsk_f2key(x.y);
-        kreg[4 * v + 2] = hsk_f2key(x.z);
-        kreg[4 * v + 3] = hsk_f2key(x.w);
+        const bool some = c0 + 3 >= 0 && c0 < cols;
+        const float4 x = *reinterpret_cast<const float4*>(row + (some ? c0 : -shift));   // 16-byte aligned by construction
+        kreg[4 * v + 0] = (unsigned)(c0 + 0) < (unsigned)cols ? hsk_f2key(x.x) : 0u;
+        kreg[4 * v + 1] = (unsigned)(c0 + 1) < (unsigned)cols ? hsk_f2key(x.y) : 0u;
+        kreg[4 * v + 2] = (unsigned)(c0 + 2) < (unsigned)cols ? hsk_f2key(x.z) : 0u;
+        kreg[4 * v + 3] = (unsigned)(c0 + 3) < (unsigned)cols ? hsk_f2key(x.w) : 0u;
       }
     }
+    if (by_maxima) {
+      uint32_t mx = 0;
+#pragma unroll
+      for (int i = 0; i < TOPK_RPT; ++i) mx = max(mx, kreg[i]);
+#if defined(HSK_TOPK_STOP) && HSK_TOPK_STOP == 1
+      if (mx == 12345u) out_vals[0] = 1.f;
+      return;
+#endif
+      const int lane = tid & 63;
+      const int cth = (k + 3) >> 2;        // <= 64
+      int gt = 0, ge = 0;
+#pragma unroll 8
+      for (int j = 0; j < 64; ++j) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mx, j);
+        gt += (o > mx) ? 1 : 0;
+        ge += (o >= mx) ? 1 : 0;
+      }
+      const unsigned long long holds = __ballot(gt < cth && cth <= ge);   // never empty: the cth-th largest exists
+      const uint32_t Lw = (uint32_t)__builtin_amdgcn_readlane((int)mx, __builtin_ctzll(holds));
+      if (lane == 0) wave_cnt[tid >> 6] = Lw;
+      __syncthreads();
+      const uint32_t L = min(min(wave_cnt[0], wave_cnt[1]), min(wave_cnt[2], wave_cnt[3]));
+      int mine_ge = 0;
+#pragma unroll
+      for (int i = 0; i < TOPK_RPT; ++i) mine_ge += (kreg[i] >= L) ? 1 : 0;
+      // where this thread's candidates go: an exclusive scan of the counts over the workgroup (no atomics: ~k returning
+      // LDS atomics on one word were a serial chain of their own)
+      const int incl = hsk_topk_wave_incl_scan(mine_ge, lane);
+      if (lane == 63) wave_tot[tid >> 6] = (unsigned)incl;
+#if defined(HSK_TOPK_STOP) && HSK_TOPK_STOP == 2
+      if (incl == 12345) out_vals[0] = 1.f;
+      return;
+#endif
+      __syncthreads();
+      unsigned int before = 0, total = 0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        const unsigned int t = wave_tot[ww];
+        before += (ww < (tid >> 6)) ? t : 0u;
+        total += t;
+      }
+      my_off = before + (unsigned)(incl - mine_ge);
+      mx_b1 = L;
+      // L == 0 (a wave with fewer than cth columns): everything is a candidate -> the general selection below
+      mx_cand = L ? total : (unsigned)TOPK_CAND_MAX + 1u;
+    } else {
     __syncthreads();
     if (in_regs) {
 #pragma unroll
@@ -748,8 +817,9 @@ __device__ __forceinline__ void hsk_topk_rows_body(const float* __restrict__ X, 
       }
     }
     __syncthreads();
-    unsigned int b1 = sh_prefix, n_cand = sh_ngt + sh_neq;
-    int cshift = in_regs ? 24 : 20;   // candidates: keys with (key >> cshift) >= b1
+    }
+    unsigned int b1 = by_maxima ? mx_b1 : sh_prefix, n_cand = by_maxima ? mx_cand : sh_ngt + sh_neq;
+    int cshift = by_maxima ? 0 : in_regs ? 24 : 20;   // candidates: keys with (key >> cshift) >= b1
     while (in_regs && cshift >= 8 && n_cand > 2u * (unsigned)kpad) {
       // 8 more bits among the keys that share the current prefix
       __syncthreads();
@@ -776,9 +846,16 @@ __device__ __forceinline__ void hsk_topk_rows_body(const float* __restrict__ X, 
       int npad = 1;
       while (npad < (int)n_cand) npad <<= 1;
       if (npad < kpad) npad = kpad;
-      for (int c = tid; c < npad; c += 256) cand[c] = 0ull;   // pads sort last
-      __syncthreads();
-      if (in_regs) {
+      if (!by_maxima || n_cand > 256) {   // (ranking by counting reads cand[0 .. n_cand) only, and by_maxima has not
+        for (int c = tid; c < npad; c += 256) cand[c] = 0ull;   // touched LDS: no pads, no barrier)   pads sort last
+        __syncthreads();
+      }
+      if (by_maxima) {
+        unsigned int slot = my_off;
+#pragma unroll
+        for (int i = 0; i < TOPK_RPT; ++i)
+          if (kreg[i] >= b1) cand[slot++] = ((unsigned long long)kreg[i] << 32) | (uint32_t)(~(uint32_t)col_of(i));
+      } else if (in_regs) {
 #pragma unroll
         for (int i = 0; i < TOPK_RPT; ++i) {
           const int c = col_of(i);
@@ -796,13 +873,26 @@ __device__ __forceinline__ void hsk_topk_rows_body(const float* __restrict__ X, 
           }
         }
       }
+      if (n_cand <= 256 && tid < 8) cand[n_cand + tid] = 0ull;   // (nobody's slot: see the ranking loop below)
       __syncthreads();
+#if defined(HSK_TOPK_STOP) && HSK_TOPK_STOP == 3
+      if (cand[0] == 12345ull) out_vals[0] = 1.f;
+      return;
+#endif
       if (n_cand <= 256) {
         // a few keys beyond k: every thread ranks its own candidate by counting the larger ones (composite keys are
         // unique; broadcast LDS reads) -- one pass instead of the 36 barrier-separated stages of a bitonic sort
+        // (eight LDS reads in flight per step: one read per iteration was a chain of n_cand LDS latencies; the slots up
+        // to the next multiple of 8 were zeroed in front of the barrier above and rank nobody down)
         const unsigned long long mine = (tid < (int)n_cand) ? cand[tid] : 0ull;
         int rank = 0;
-        for (int j = 0; j < (int)n_cand; ++j) rank += (cand[j] > mine) ? 1 : 0;
+        for (int j = 0; j < (int)n_cand; j += 8) {
+          unsigned long long o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = cand[j + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rank += (o[q] > mine) ? 1 : 0;
+        }
         if (tid < (int)n_cand && rank < k) {
           out_vals[(long long)blockIdx.x * k + rank] = hsk_key2f((uint32_t)(mine >> 32));
           out_idx[(long long)blockIdx.x * k + rank] = (IdxOut)((long long)(~(uint32_t)mine) + idx_offset);

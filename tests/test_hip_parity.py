@@ -802,12 +802,13 @@ def test_topk_dense_ties_and_neg_inf(ops, oracle):
     assert idx.dtype == torch.int64
 
 
-def test_topk_wide_rows_fast_path_and_fallback(ops, oracle):
-    """cols >= 4096 takes the two-pass path (12-bit histogram, candidates sorted in LDS); rows whose candidate bin
-    overflows LDS (long runs of equal values) fall back to the 4 x 8-bit radix select.  Exact ids either way."""
+@pytest.mark.parametrize('C', [9000, 16000])
+def test_topk_wide_rows_fast_path_and_fallback(ops, oracle, C):
+    """cols >= 4096: the row is held in registers (up to 12 288 / 16 384 columns: two kernels) and the candidates are
+    the keys >= the k-th largest per-thread maximum (k <= 256), else a histogram's; rows whose candidates overflow LDS
+    (long runs of equal values) fall back to the 4 x 8-bit radix select.  Exact ids either way."""
     g = torch.Generator(device='cuda').manual_seed(4)
-    C = 9000
-    x = torch.randn(8, C, device='cuda', generator=g)
+    x = torch.randn(10, C, device='cuda', generator=g)
     x[1] = (x[1] * 2).round() / 2                         # ~1500 values per level: ties inside the candidate bin
     x[2, :] = 0.25                                        # one value everywhere: > 2048 candidates -> fallback
     x[3, :] = float('-inf'); x[3, ::97] = torch.randn(len(range(0, C, 97)), device='cuda', generator=g)   # 93 finite < k
@@ -815,11 +816,18 @@ def test_topk_wide_rows_fast_path_and_fallback(ops, oracle):
     x[5, 4000:] = float('-inf')                           # the exclusion mask of a heavy user
     x[6] = -x[0]
     x[7] = torch.arange(C, device='cuda', dtype=torch.float32) % 50  # 180 copies of each level, k cuts through one
-    for k in (100, 5):
+    x[8] = -torch.arange(C, device='cuda', dtype=torch.float32)      # sorted along the columns: the top k sit in a few
+    x[9] = torch.arange(C, device='cuda', dtype=torch.float32)       # threads' registers (more candidates than 256)
+    for k in (100, 5, 256, 300):
         vals, idx = ops.topk_dense(x, k)
         rv, ri = oracle.topk(x.cpu().numpy(), k)
         assert np.array_equal(idx.cpu().numpy(), ri), k
         assert np.array_equal(vals.cpu().numpy(), rv), k
+    # an odd width (the ml10m catalogue): rows start at every offset from a 16-byte boundary (the shifted pieces)
+    y = torch.randn(9, 10677, device='cuda', generator=g)
+    vals, idx = ops.topk_dense(y, 100)
+    rv, ri = oracle.topk(y.cpu().numpy(), 100)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
 
 
 def test_rank_metrics_vs_reference_functions(ops):
