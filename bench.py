@@ -281,8 +281,10 @@ def run_cfg5(device, steps, warmup, comm=None):
         c.all_reduce(ok)
     if int(ok.item()) != (1 if share else W):
         raise RuntimeError(f'cfg5 build failed on rank {r}: {err}' if err is not None else 'cfg5 build failed on another rank')
+    lazy_items = {'0': False, '1': True}.get(os.environ.get('HSK_CFG5_LAZY_ITEMS', ''), 'auto')   # (experiments)
     st = ShardedBprMf(c, tabs['user_emb'], tabs['item_emb'], tabs['item_bias'], None, None, lr=LR, wd=WD, batch=B,
-                      n_neg=N, seed=64, inputs_are_shards=True, n_users=U, n_items=I, **data.device_arrays())
+                      n_neg=N, seed=64, inputs_are_shards=True, n_users=U, n_items=I, lazy_items=lazy_items,
+                      **data.device_arrays())
     del tabs
     if share:
         st.rows_all.normal_(std=0.1 / D)          # the absent peers' user rows
@@ -340,6 +342,21 @@ def run_cfg5(device, steps, warmup, comm=None):
                 'frac_of_measured_hbm_gather_5750': ach / HBM_GATHER_GBS, 'traffic': None, 'avg_us': fwd_us,
                 'launches': int(timing['fwd'][1]), 'algorithmic_bytes_per_launch': by,
                 'item_shard_GB': 4.0 * D * st.item_emb.shape[0] / 1e9, 'kept_entries_per_step': kept}
+    # the step's DOMINANT kernel at this shape is not the gather but the item pass: 73 % of the shard's rows have an entry
+    # in every global batch, so AdamW sweeps the whole shard (p, m, v read and written) and gathers a user row per entry
+    item_us = stage.get('item')
+    item_roof = None
+    if item_us:
+        I_loc = st.item_emb.shape[0]
+        dense = not bool(st.sh.base.lazy_items)
+        rows = I_loc if dense else min(I_loc, kept)
+        by_i = 24 * D * rows + 4 * D * kept + 12 * kept
+        ach_i = by_i / (item_us * 1e-6) / 1e9
+        item_roof = {'bound': 'hbm', 'kernel': 'k_item_update_sliced (item-major gradient reduction over the kept entries + AdamW on '
+                     + ('every row of the shard' if dense else 'the touched rows') + ')',
+                     'achieved': ach_i, 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'frac': ach_i / HBM_PEAK_GBS,
+                     'frac_of_measured_copy_6290': ach_i / 6290.0, 'avg_us': item_us, 'algorithmic_bytes_per_launch': by_i,
+                     'share_of_step': item_us * 1e-3 / (elapsed * 1e3 / steps)}
     ms = elapsed * 1e3 / steps
     amort = (flush_ms / fu) if fu < (1 << 29) else 0.0
     out = {'workload': f'configs[4]: synthetic U={U}, I={I} ({data.nnz} interactions generated on device), mf + bpr + adamw, '
@@ -348,7 +365,7 @@ def run_cfg5(device, steps, warmup, comm=None):
            'n_gpus_of_the_job': W, 'ranks_running': 1 if share else W,
            'ms_per_step': ms, 'ms_per_step_with_amortised_sweep': ms + amort, 'steps': steps, 'warmup': warmup,
            'triplets_per_step_global': G * N, 'loss_last_step' + ('_local_share' if share else ''): loss,
-           'stage_us_per_step': stage, 'roofline': roof,
+           'stage_us_per_step': stage, 'roofline': roof, 'roofline_item_pass': item_roof,
            'lazy_sweep': {'cadence_steps_users': fu if fu < (1 << 29) else None,
                           'cadence_steps_items': fi if fi < (1 << 29) else None, 'sweep_ms': flush_ms,
                           'amortised_ms_per_step': amort},

@@ -639,7 +639,11 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
   const int n_sl = (int)hsk_ceil_div(D, 64 * vs);
   // merged launch at a small batch: whole-row item workgroups (n_slices_pad = 0 tells the kernel), see hsk_item_row_body
   static const int rows_on = getenv("HSK_ITEM_ROWS") ? atoi(getenv("HSK_ITEM_ROWS")) : 1;
-  const bool whole_rows = APPLY && ua && rows_on && n_entries <= 64 * 1024 && !part;
+  // lazy item AdamW (catalogues far beyond the caches): whole rows as well -- the launch is p / m / v traffic on the
+  // touched rows, 2 KB contiguous per row and table instead of two 1 KB halves (hbm workload: 1042 -> 977 us), and the
+  // slices' L2 affinity buys nothing for a gather that is a tenth of the bytes
+  static const int rows_lazy = getenv("HSK_ITEM_ROWS_LAZY") ? atoi(getenv("HSK_ITEM_ROWS_LAZY")) : 1;
+  const bool whole_rows = APPLY && ua && rows_on && (n_entries <= 64 * 1024 || (rows_lazy && st->lazy_items)) && !part;
   const int n_slices_pad = whole_rows ? 0 : (n_sl < 8 && 8 % n_sl == 0) ? n_sl : (int)hsk_align_up(n_sl, 8);
   const bool lazy = APPLY && st->lazy_items;
   // lazy item AdamW: only the items with entries (the sort's `touched` list; at most one per entry)
@@ -679,6 +683,19 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
     if (gen) { if (lazy) HSK_ITEM_USER(VSC, true, true); else HSK_ITEM_USER(VSC, true, false); }
     else     { if (lazy) HSK_ITEM_USER(VSC, false, true); else HSK_ITEM_USER(VSC, false, false); }
 #undef HSK_ITEM_USER
+    return;
+  }
+  static const int rows_big = getenv("HSK_ITEM_ROWS_BIG") ? atoi(getenv("HSK_ITEM_ROWS_BIG")) : 0;
+  if (APPLY && !part && rows_big) {
+    const unsigned nb = (unsigned)hsk_ceil_div(n_list, 4);
+    hsk_item_args ir = ia;
+    ir.n_slices_pad = 0;
+    if constexpr (APPLY) {
+      if (gen) { if (lazy) k_item_update_rows<V, NCH, FULL, true, true><<<nb, 256, 0, stream>>>(ir);
+                 else      k_item_update_rows<V, NCH, FULL, true, false><<<nb, 256, 0, stream>>>(ir); }
+      else     { if (lazy) k_item_update_rows<V, NCH, FULL, false, true><<<nb, 256, 0, stream>>>(ir);
+                 else      k_item_update_rows<V, NCH, FULL, false, false><<<nb, 256, 0, stream>>>(ir); }
+    }
     return;
   }
 #define HSK_ITEM_SLICED(VS, GEN, LZ)                                                   \
