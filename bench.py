@@ -235,7 +235,7 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
                data=data, csr=csr, nnz=nnz, steps=steps, warmup=warmup, graph_replays=n_replays, pure_us=pure_us,
                flush_us=flush_us, flush_cadence=st.flush_cadence(B) if comm is None else st.flush_cadence(),
                lazy_users=bool(st.st.lazy_users) if comm is None else True,
-               parts=(st.batch_columns(B, N + 1) - N) if comm is None else 1)
+               parts=(st.batch_columns(B, N + 1) - N) if comm is None else 1, world=world, sharded=comm is not None)
     if all_stages:
         out['stage_us_per_step'] = {k: v[0] * 1e3 / max(v[1], 1) for k, v in timing.items()}
     del st
@@ -393,7 +393,12 @@ def roofline_of(workload, r):
     """Roofline object of the gather+BPR kernel for one workload.  `bound` names what the gathered tables sit in."""
     if not r['fwd_us']:
         return None
+    W = r.get('world', 1)
     by = fwd_read_bytes(r['B'], r['N'], r['D'])
+    if r.get('sharded'):
+        # k_shard_fwd of ONE rank: a user row per positive of the GLOBAL batch (from the exchange buffer) + an item row per
+        # kept entry -- the rank owns 1/W of the catalogue, so it keeps B (1 + N) of the W B (1 + N) entries on average
+        by += 4 * r['D'] * r['B'] * (W - 1) + 12 * r['B'] * (W - 1)
     achieved = by / (r['fwd_us'] * 1e-6) / 1e9
     d = r['data']
     table_mb = 4.0 * r['D'] * d.n_items / 1e6
@@ -407,6 +412,12 @@ def roofline_of(workload, r):
         kernel = 'k_fwd_part, P = %d (gather + scores + BPR + partial user-row grads; the next batch\'s lazy user rows brought up to date by workgroups of the same launch)' % parts
         peak_source = ('MI355X_MICROARCH.md, "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs\' L2s (mid-point); '
                        'each XCD gathers from %.1f MB of the %.1f MB item table' % (table_mb / parts, table_mb))
+    elif r.get('sharded') and table_mb / W <= 4.0:
+        # a rank's range shard of the item table fits every XCD's 4 MB L2
+        bound, peak = 'l2', L2_GATHER_GBS
+        kernel = 'k_shard_fwd'
+        peak_source = ('MI355X_MICROARCH.md, "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs\' L2s (mid-point); '
+                       'this rank gathers from its %.1f MB shard of the %.1f MB item table' % (table_mb / W, table_mb))
     elif cached:
         bound, peak = 'infinity-cache', ICACHE_GATHER_GBS
         kernel = 'k_fwd_ugrad (gather + scores + BPR + user-row grad)'
@@ -436,7 +447,7 @@ def roofline_of(workload, r):
                               'frac_of_hbm_spec_8000': pa / HBM_PEAK_GBS,
                               'note': 'st.catchup_apart = 1, 32 eager steps after the timed region'}
     # the metric's own roofline: whole step against algorithmic gather bytes at the HBM spec peak
-    out['step_frac_of_hbm_roofline'] = r['value'] / (HBM_PEAK_GBS * 1e9 / (by / (r['B'] * r['N'])))
+    out['step_frac_of_hbm_roofline'] = r['value'] / W / (HBM_PEAK_GBS * 1e9 / (fwd_read_bytes(r['B'], r['N'], r['D']) / (r['B'] * r['N'])))
     return out
 
 
