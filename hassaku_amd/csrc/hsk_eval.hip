@@ -742,15 +742,14 @@ __device__ __forceinline__ void hsk_topk_rows_body(const float* __restrict__ X, 
 #endif
       const int lane = tid & 63;
       const int cth = (k + 3) >> 2;        // <= 64
-      int gt = 0, ge = 0;
-#pragma unroll 8
-      for (int j = 0; j < 64; ++j) {
-        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mx, j);
-        gt += (o > mx) ? 1 : 0;
-        ge += (o >= mx) ? 1 : 0;
+      // the cth-th largest of the wave's 64 maxima, bit by bit from the top: the largest T with >= cth maxima >= T (one
+      // compare + a scalar population count per bit; ranking every lane against every other took 64 x 5 vector operations)
+      uint32_t Lw = 0;
+#pragma unroll
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t t = Lw | (1u << bit);
+        if (__popcll(__ballot(mx >= t)) >= cth) Lw = t;
       }
-      const unsigned long long holds = __ballot(gt < cth && cth <= ge);   // never empty: the cth-th largest exists
-      const uint32_t Lw = (uint32_t)__builtin_amdgcn_readlane((int)mx, __builtin_ctzll(holds));
       if (lane == 0) wave_cnt[tid >> 6] = Lw;
       __syncthreads();
       const uint32_t L = min(min(wave_cnt[0], wave_cnt[1]), min(wave_cnt[2], wave_cnt[3]));
