@@ -142,13 +142,23 @@ __global__ __launch_bounds__(256) void k_sort_rowscan(int* __restrict__ hist, hs
 __device__ __forceinline__ void hsk_bucket_starts(const int* __restrict__ btot, int nb, int* bs) {
   const int lane = threadIdx.x & 63;
   if ((threadIdx.x >> 6) == 0) {
+    // every total loaded before the first is scanned (a load per loop iteration made the head of every scatter
+    // workgroup a chain of up to 8 memory latencies)
+    int v[HSK_SORT_MAX_BUCKETS / 64];
+#pragma unroll
+    for (int q = 0; q < HSK_SORT_MAX_BUCKETS / 64; ++q) {
+      const int j = q * 64 + lane;
+      v[q] = (j < nb) ? btot[j] : 0;
+    }
     int carry = 0;
-    for (int j0 = 0; j0 < nb; j0 += 64) {
-      const int j = j0 + lane;
-      const int v = (j < nb) ? btot[j] : 0;
-      const int incl = hsk_wave_incl_scan(v, lane);
-      if (j < nb) bs[j] = carry + incl - v;
-      carry += __shfl(incl, 63, 64);
+#pragma unroll
+    for (int q = 0; q < HSK_SORT_MAX_BUCKETS / 64; ++q) {
+      const int j = q * 64 + lane;
+      if (q * 64 < nb) {   // wave-uniform
+        const int incl = hsk_wave_incl_scan(v[q], lane);
+        if (j < nb) bs[j] = carry + incl - v[q];
+        carry += __shfl(incl, 63, 64);
+      }
     }
     if (lane == 0) bs[nb] = carry;
   }

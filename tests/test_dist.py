@@ -299,15 +299,30 @@ def _single_gpu_reference(world, shape, n_steps, lazy_items='auto'):
                              lazy_items=lazy_items)
     order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
     n_slices = len(pairs) // G
-    losses = []
+    losses, batches = [], []
     for s in range(n_steps):
         st.step_sampled(order, (s % n_slices) * G, G, N)
         if s % 9 == 0:
             losses.append(st.last_loss())
+        bu, bi = st.last_batch(G, N + 1)      # the global batch the device sampler drew for this step
+        batches.append((bu.cpu().numpy(), bi.cpu().numpy()))
     st.flush()
     st.check_status()
     lu, li = st.last_batch(G, N + 1)
-    return t, np.array(losses), lu.cpu().numpy(), li.cpu().numpy()
+    return t, np.array(losses), lu.cpu().numpy(), li.cpu().numpy(), batches
+
+
+def _oracle_replay(shape, batches):
+    """The same global batches through the CPU oracle (dense AdamW on every row, every step)."""
+    from oracle import oracle as orc
+    U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
+    tr = orc.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], P['user_bias'], None, lr=2e-3, wd=1e-4)
+    losses = []
+    for s, (u, it) in enumerate(batches):
+        loss, _, _, _ = tr.step(u.astype(np.int64), it.astype(np.int64))
+        if s % 9 == 0:
+            losses.append(float(loss))
+    return tr.P, np.array(losses)
 
 
 def _check_against_single_gpu(tmp_path, world, shape, n_steps):
@@ -315,7 +330,7 @@ def _check_against_single_gpu(tmp_path, world, shape, n_steps):
     from hassaku_amd import hip_ops as ops
     from hassaku_amd.data.csr import UserItemCsr
     r = np.load(os.path.join(str(tmp_path), 'mp.npz'))
-    t, losses, lu, li = _single_gpu_reference(world, shape, n_steps)
+    t, losses, lu, li, batches = _single_gpu_reference(world, shape, n_steps)
     U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
     # the samples: each rank kept exactly the entries of the single-GPU batch that fall into its item range,
     # positive first, negatives in column order
@@ -331,6 +346,14 @@ def _check_against_single_gpu(tmp_path, world, shape, n_steps):
     assert_adam_param_close(r['Ub'], t['user_bias'].cpu().numpy(), 'user_bias')
     assert_adam_param_close(r['I'], t['item_emb'].cpu().numpy(), 'item_emb')
     assert_adam_param_close(r['Ib'], t['item_bias'].cpu().numpy(), 'item_bias')
+    # ... and DIRECTLY against the oracle: the batches above (each rank's kept entries were just shown to be exactly
+    # their entries in its item range) replayed through the CPU restatement of the reference's dense step
+    oP, olosses = _oracle_replay(shape, batches)
+    np.testing.assert_allclose(r['losses'], olosses, rtol=2e-5)
+    assert_adam_param_close(r['U'], oP['user_emb'], 'user_emb vs oracle')
+    assert_adam_param_close(r['I'], oP['item_emb'], 'item_emb vs oracle')
+    assert_adam_param_close(r['Ib'], oP['item_bias'], 'item_bias vs oracle')
+    assert_adam_param_close(r['Ub'], oP['user_bias'], 'user_bias vs oracle')
     # item-sharded evaluation == single-GPU evaluation of the gathered tables
     lab = UserItemCsr.from_pairs(val[:, 0], val[:, 1], U, I)
     exc = UserItemCsr.from_pairs(pairs[:, 0], pairs[:, 1], U, I)
