@@ -818,7 +818,7 @@ def test_topk_wide_rows_fast_path_and_fallback(ops, oracle, C):
     x[7] = torch.arange(C, device='cuda', dtype=torch.float32) % 50  # 180 copies of each level, k cuts through one
     x[8] = -torch.arange(C, device='cuda', dtype=torch.float32)      # sorted along the columns: the top k sit in a few
     x[9] = torch.arange(C, device='cuda', dtype=torch.float32)       # threads' registers (more candidates than 256)
-    for k in (100, 5, 256, 300):
+    for k in (100, 5, 1, 2, 256, 300):
         vals, idx = ops.topk_dense(x, k)
         rv, ri = oracle.topk(x.cpu().numpy(), k)
         assert np.array_equal(idx.cpu().numpy(), ri), k
