@@ -685,19 +685,6 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
 #undef HSK_ITEM_USER
     return;
   }
-  static const int rows_big = getenv("HSK_ITEM_ROWS_BIG") ? atoi(getenv("HSK_ITEM_ROWS_BIG")) : 0;
-  if (APPLY && !part && rows_big) {
-    const unsigned nb = (unsigned)hsk_ceil_div(n_list, 4);
-    hsk_item_args ir = ia;
-    ir.n_slices_pad = 0;
-    if constexpr (APPLY) {
-      if (gen) { if (lazy) k_item_update_rows<V, NCH, FULL, true, true><<<nb, 256, 0, stream>>>(ir);
-                 else      k_item_update_rows<V, NCH, FULL, true, false><<<nb, 256, 0, stream>>>(ir); }
-      else     { if (lazy) k_item_update_rows<V, NCH, FULL, false, true><<<nb, 256, 0, stream>>>(ir);
-                 else      k_item_update_rows<V, NCH, FULL, false, false><<<nb, 256, 0, stream>>>(ir); }
-    }
-    return;
-  }
 #define HSK_ITEM_SLICED(VS, GEN, LZ)                                                   \
   do {                                                                                 \
     if (part) {                                                                        \
