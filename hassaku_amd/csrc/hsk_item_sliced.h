@@ -12,7 +12,10 @@
 #include "hsk_step_kernels.h"
 
 #ifndef HSK_ITEM_MLP
-#define HSK_ITEM_MLP 8     // user-row loads a wave keeps in flight
+// user-row loads a wave keeps in flight.  4: with 8 the kernel sat on its 64-VGPR budget (8 waves per SIMD) with spills
+// -- measured per step at the ml10m shape, three alternations on one box: 2 / 3 / 4: 188, 6: 190, 8: 194, 12: 238 us;
+// 4 against 8 elsewhere: lfm2b-shaped training 509 against 560 us, the cfg5 share's item pass 6.26 against 6.38 ms
+#define HSK_ITEM_MLP 4
 #endif
 #ifndef HSK_ITEM_NT
 #define HSK_ITEM_NT 0      // 1: the item rows (p, m, v: read once, written once per step) move with non-temporal hints
