@@ -22,6 +22,9 @@
 #include <utility>
 #include <vector>
 
+#ifndef HSK_FWD_R
+#define HSK_FWD_R 4   // item rows per buffer of the forward kernels (two buffers in flight), rows of fewer than 16 floats per lane
+#endif
 #define HSK_ADAM_TAB_LEN 65536   // per-step (step_size, bc2_sqrt) table for the lazy replay
 #define HSK_FLUSH_NEVER (1 << 30) // cadence of a table whose periodic sweep never pays (an explicit flush still sweeps)
 
@@ -905,7 +908,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     constexpr int V = decltype(v_)::value;
     constexpr int NCH = decltype(n_)::value;
     constexpr bool FULL = decltype(f_)::value;
-    constexpr int R = (V * NCH >= 16) ? 2 : 4;
+    constexpr int R = (V * NCH >= 16) ? 2 : HSK_FWD_R;
     // lazy user AdamW: the forward replays the pending zero-gradient steps of its user row in registers and leaves
     // the current row in ucur (no separate catch-up launch, no rewrite of the row before the owner's update).
     // st->catchup_apart: a stand-alone catch-up launch in front instead -- at B = 4096 the replay is ~9 us of pure VALU
@@ -1047,7 +1050,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
     constexpr int V = decltype(v_)::value;
     constexpr int NCH = decltype(n_)::value;
     constexpr bool FULL = decltype(f_)::value;
-    constexpr int R = (V * NCH >= 16) ? 2 : 4;
+    constexpr int R = (V * NCH >= 16) ? 2 : HSK_FWD_R;
     // user update: the owners' rows (lazy: pending steps were replayed by the forward) or a dense sweep over the
     // table; + one workgroup for the loss reduction / global bias.  Even D: in the item pass's own launch.
     const hsk_finish_args fin = {w.loss_b, (int)(B * n_part), inv_bn_d, st->loss_out, st->global_bias,
