@@ -349,11 +349,11 @@ def run_cfg5(device, steps, warmup, comm=None):
     if item_us:
         I_loc = st.item_emb.shape[0]
         dense = not bool(st.sh.base.lazy_items)
-        rows = I_loc if dense else min(I_loc, kept)
+        rows = I_loc if dense else I_loc * (1.0 - float(np.exp(-kept / I_loc)))   # rows with an entry in the batch
         by_i = 24 * D * rows + 4 * D * kept + 12 * kept
         ach_i = by_i / (item_us * 1e-6) / 1e9
-        item_roof = {'bound': 'hbm', 'kernel': 'k_item_update_sliced (item-major gradient reduction over the kept entries + AdamW on '
-                     + ('every row of the shard' if dense else 'the touched rows') + ')',
+        item_roof = {'bound': 'hbm', 'kernel': ('k_item_update_sliced' if dense else 'k_item_update_rows') + ' (item-major gradient reduction over the kept entries + AdamW on '
+                     + ('every row of the shard' if dense else 'the rows with entries (lazy, exact; their catch-up before the forward is a launch of its own)') + ')',
                      'achieved': ach_i, 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'frac': ach_i / HBM_PEAK_GBS,
                      'frac_of_measured_copy_6290': ach_i / 6290.0, 'avg_us': item_us, 'algorithmic_bytes_per_launch': by_i,
                      'share_of_step': item_us * 1e-3 / (elapsed * 1e3 / steps)}

@@ -688,6 +688,20 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
 #undef HSK_ITEM_USER
     return;
   }
+  // lazy item AdamW without the user update in the launch (the sharded step): whole rows, as in the merged launch above
+  // (one rank's share of configs[4], 73 % of the 1.25 M x 4 KB rows touched per step: item pass 5.34 -> 4.88 ms, which is
+  // what makes the lazy update the faster one there: 7.55-7.63 against 7.92 ms per step for the dense sweep)
+  static const int rows_shard = getenv("HSK_ITEM_ROWS_SHARD") ? atoi(getenv("HSK_ITEM_ROWS_SHARD")) : 1;
+  if (APPLY && !part && lazy && rows_shard) {
+    const unsigned nb = (unsigned)hsk_ceil_div(n_list, 4);
+    hsk_item_args ir = ia;
+    ir.n_slices_pad = 0;
+    if constexpr (APPLY) {
+      if (gen) k_item_update_rows<V, NCH, FULL, true, true><<<nb, 256, 0, stream>>>(ir);
+      else     k_item_update_rows<V, NCH, FULL, false, true><<<nb, 256, 0, stream>>>(ir);
+    }
+    return;
+  }
 #define HSK_ITEM_SLICED(VS, GEN, LZ)                                                   \
   do {                                                                                 \
     if (part) {                                                                        \

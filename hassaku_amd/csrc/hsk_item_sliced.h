@@ -286,6 +286,12 @@ __global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
   hsk_item_sliced_body<APPLY, VS, GEN, LAZY, PART>(a, (int)blockIdx.x);
 }
 
+// whole rows as a launch of their own: the sharded step's item pass over the TOUCHED rows of a shard (lazy item AdamW)
+template <int V, int NCH, bool FULL, bool GEN, bool LAZY>
+__global__ __launch_bounds__(256) void k_item_update_rows(hsk_item_args a) {
+  hsk_item_row_body<V, NCH, FULL, GEN, LAZY>(a, (int)blockIdx.x);
+}
+
 // The item pass and the owners' user-row update in ONE launch: the first n_user_blocks workgroups (a multiple of 8, so
 // that the item workgroups keep their XCD affinity) are k_user_update_lazy's, the rest k_item_update_sliced's.  The two
 // are independent once the item pass reads the batch's user rows from `ucur` instead of the table the owners rewrite:

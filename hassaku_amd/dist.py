@@ -337,8 +337,13 @@ class ShardedBprMf:
         st.lazy_users = 1
         st.ws_sharded, st.flush_every = 1, int(flush_every)
         st.graph_chunk, st.catchup_apart = -1, 0
-        if lazy_items == 'auto':   # worth it when most of the shard's rows are outside every batch
-            lazy_items = D % 2 == 0 and I_loc >= 2 * cap and I_loc * D > hip_ops.LAZY_USERS_MIN_ELEMENTS
+        if lazy_items == 'auto':
+            # Worth it while a batch leaves enough of the shard's rows alone.  With a fraction f = 1 - exp(-entries / rows)
+            # of the rows touched per step the dense sweep moves 6 row-units (p, m, v read and written) per row, the lazy
+            # update 6 f for the touched rows + 4 f (1 - f) for the catch-up of those that skipped a step, at a somewhat
+            # lower rate per byte (random whole rows instead of a stream): measured break-even f ~ 0.8 (configs[4]: f =
+            # 0.73, 7.6 against 7.9 ms per step) -- i.e. entries / rows < 1.5.
+            lazy_items = D % 2 == 0 and I_loc >= 0.66 * cap and I_loc * D > hip_ops.LAZY_USERS_MIN_ELEMENTS
         st.lazy_items = 1 if lazy_items else 0
         st.timing_mask, st.timing, st.aux, st.timing_every, st.timing_now = 0, None, None, 1, 0
         st.loss_kind, st.ssm_log_adjust = hip_ops.LOSS_KINDS[loss], float(log_adjust)
