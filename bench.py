@@ -720,6 +720,16 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    # The two legs that run in child processes go FIRST, while this process holds nothing on the device: one rank's
+    # 169 GB share of configs[4] gathers random 4 KB rows out of tables that large, and it ran 9 % slower (item pass 5.57
+    # against 4.92 ms) as a child of a parent that had already been through its other legs than from a fresh process.
+    children = {}
+    if comm is None and not args.only:
+        # BASELINE configs[4] needs 8 GPUs; what one GPU can show is one rank's full-size share of it
+        children['cfg5_shard'] = guarded(run_cfg5_share_child, device)
+        # the multi-GPU code path on this one GPU (a 1-rank RCCL group: every kernel, every collective call and stream
+        # hand-off of the sharded step, no link traffic): what the step costs before any xGMI link is involved
+        children['sharded_1rank'] = guarded(run_sharded_1rank, args.workload, device)
     r = run_training(args.workload, device, args.steps, args.warmup, comm=comm, prefetch=not args.no_prefetch,
                      lazy_users=False if args.dense_users else True if args.lazy_users else 'auto',
                      all_stages=args.time_all_stages, pure_gather=not args.no_pure_gather)
@@ -763,11 +773,8 @@ def main():
                     'steps_issued_as_replayed_graphs': 64 * x['graph_replays'],
                     'roofline': roofline_of(name, x)}
             out['eval'] = {s: run_eval(s, device) for s in ('ml10m', 'lfm2b')}
-            # BASELINE configs[4] needs 8 GPUs; what one GPU can show is one rank's full-size share of it
-            out['workloads']['cfg5_shard'] = guarded(run_cfg5_share_child, device)
-            # the multi-GPU code path on this one GPU (a 1-rank RCCL group: every kernel, every collective call and
-            # stream hand-off of the sharded step, no link traffic): what the step costs before any xGMI link is involved
-            out['sharded_1rank'] = guarded(run_sharded_1rank, args.workload, device)
+            out['workloads']['cfg5_shard'] = children['cfg5_shard']
+            out['sharded_1rank'] = children['sharded_1rank']
         else:
             out['eval'] = {'lfm2b': run_eval('lfm2b', device, comm)}
             if world == CFG5['world']:     # the one place the whole configs[4] job can run
