@@ -724,6 +724,9 @@ def main():
     # 169 GB share of configs[4] gathers random 4 KB rows out of tables that large, and it ran 9 % slower (item pass 5.57
     # against 4.92 ms) as a child of a parent that had already been through its other legs than from a fresh process.
     children = {}
+    if comm is not None and world == CFG5['world'] and not args.only and args.workload != 'cfg5':
+        # (the same for the one place the whole configs[4] job can run: before this process's other legs)
+        children['cfg5'] = guarded(run_cfg5, device, 12, 4, comm)
     if comm is None and not args.only:
         # BASELINE configs[4] needs 8 GPUs; what one GPU can show is one rank's full-size share of it
         children['cfg5_shard'] = guarded(run_cfg5_share_child, device)
@@ -777,8 +780,8 @@ def main():
             out['sharded_1rank'] = children['sharded_1rank']
         else:
             out['eval'] = {'lfm2b': run_eval('lfm2b', device, comm)}
-            if world == CFG5['world']:     # the one place the whole configs[4] job can run
-                out['workloads'] = {'cfg5': guarded(run_cfg5, device, 12, 4, comm)}
+            if 'cfg5' in children:
+                out['workloads'] = {'cfg5': children['cfg5']}
     if cpu is not None:
         out['cpu_baseline'] = cpu
     if rank == 0:
