@@ -152,7 +152,8 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
             while s < n:
                 k0 = (first + s) % n_batches
                 m = min(n - s, n_batches - k0, 256)
-                st.hint_after_run(order, ((k0 + m) % n_batches) * B, B, N)
+                nk = (k0 + m) % n_batches   # (two batches: large batches are prepared over the two steps in front of their own)
+                st.hint_after_run(order, nk * B, B, N, n_batches=2 if nk + 2 <= n_batches else 1)
                 st.steps_sampled(order, k0 * B, m, B, N)
                 s += m
             return
@@ -185,7 +186,7 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     # 64 further (eager) steps of the same stream.  Large batches: events inside the timed region -- every stage on
     # every step when asked; otherwise only the roofline kernel, on every 8th step (every step for short runs), so that
     # the event records (each costs a few us of launch gap) do not distort the step time being measured.
-    replayed = comm is None and B < 2048 and not all_stages and prefetch
+    replayed = comm is None and (B < 2048 or os.environ.get('HSK_BENCH_REPLAYED') == '1') and not all_stages and prefetch
     names = ('prep', 'scan', 'scatter', 'fwd', 'item', 'user', 'finish') if comm is None else ('fwd', 'item', 'user')
     if not replayed:
         # an event-timed launch costs the step ~10 us (measured: 210 / 206 / 202 us per step with every 1st / 2nd / 4th

@@ -34,14 +34,16 @@ class HskBprmfState(ctypes.Structure):
         ('max_batch', c_int64), ('max_cols', c_int64),
         ('lazy_users', c_int32), ('timing_mask', c_int32),
         ('timing', c_void_p), ('aux', c_void_p),
-        ('timing_every', c_int32), ('timing_now', c_int32),
-        ('loss_kind', c_int32), ('opt_kind', c_int32), ('ssm_log_adjust', c_double),
+        ('timing_every', c_int32), ('loss_kind', c_int32),
+        ('opt_kind', c_int32), ('lazy_items', c_int32),
+        ('ssm_log_adjust', c_double),
         ('alias_prob', c_void_p), ('alias_idx', c_void_p),
-        ('lazy_items', c_int32), ('graph_chunk', c_int32),
-        ('catchup_apart', c_int32), ('reserved3', c_int32),
+        ('graph_chunk', c_int32), ('catchup_apart', c_int32),
         ('loss_out', c_void_p), ('status', c_void_p),
         ('flush_every', c_int32), ('ws_sharded', c_int32),
+        # library scratch (zero-initialised by ctypes, never written from Python)
         ('frozen_hyper', c_double * 5), ('frozen_opt', c_int32), ('frozen_valid', c_int32),
+        ('timing_now', c_int32), ('reserved3', c_int32),
     ]
 
 
@@ -56,6 +58,7 @@ class HskBprmfShard(ctypes.Structure):
         ('rows_send', c_void_p), ('rows_all', c_void_p),
         ('dU_all', c_void_p), ('grads_mine', c_void_p),
         ('s0', c_void_p), ('gsum', c_void_p),
+        ('ssm_send', c_void_p), ('ssm_all', c_void_p),
         ('cur_batch', c_int64), ('cur_cols', c_int64),
         ('cur_set', c_int32), ('phase', c_int32),
     ]
@@ -104,6 +107,8 @@ SIGNATURES = {
     'hsk_aux_destroy': (None, [c_void_p]),
     'hsk_bprmf_hint_next': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
     'hsk_bprmf_hint_after_run': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
+    'hsk_bprmf_hint_after_run_n': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64, c_int64]),
+    'hsk_bprmf_pipelined_steps': (c_int64, [POINTER(HskBprmfState)]),
     'hsk_shard_workspace_bytes': (c_int64, [c_int64] * 4),
     'hsk_shard_init': (c_int, [POINTER(HskBprmfShard), c_void_p]),
     'hsk_shard_prepare': (c_int, [POINTER(HskBprmfShard), c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p]),
@@ -118,7 +123,10 @@ SIGNATURES = {
     'hsk_shard_last_batch': (c_int, [POINTER(HskBprmfShard), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'hsk_rccl_available': (c_int, []),
     'hsk_rccl_unique_id': (c_int, [c_void_p]),
+    'hsk_hostcoll_unique_id': (c_int, [c_int64, c_void_p]),
     'hsk_shard_rt_create': (c_void_p, [c_int32, c_int32, c_void_p]),
+    'hsk_shard_rt_create_with': (c_void_p, [c_int32, c_int32, c_void_p]),
+    'hsk_shard_rt_backend': (c_char_p, [c_void_p]),
     'hsk_shard_rt_destroy': (None, [c_void_p]),
     'hsk_shard_step': (c_int, [POINTER(HskBprmfShard), c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                c_void_p]),

@@ -25,6 +25,11 @@
 #ifndef HSK_FWD_R
 #define HSK_FWD_R 4   // item rows per buffer of the forward kernels (two buffers in flight), rows of fewer than 16 floats per lane
 #endif
+#ifndef HSK_FWD_PART_R
+#define HSK_FWD_PART_R 3   // ... of the item-partitioned forward: with the riding preparation phases in the kernel, four rows
+                           // per buffer need 129 registers (three waves per SIMD); three rows: 114, and the same step time
+                           // (188.3 against 188 us, measured in round 3 before the phases rode along)
+#endif
 #define HSK_ADAM_TAB_LEN 65536   // per-step (step_size, bc2_sqrt) table for the lazy replay
 #define HSK_FLUSH_NEVER (1 << 30) // cadence of a table whose periodic sweep never pays (an explicit flush still sweeps)
 
@@ -102,6 +107,9 @@ struct hsk_ws {
   // second set of the per-batch buffers: the next batch is sampled and sorted into it while this one trains
   int *u32_b, *it32_b, *perm_b, *hist_b, *btot_b, *bstart_b, *offsets_b, *owner_b, *cnt_b;
   int2* perm1_b;
+  // third set (single-GPU step only): the in-launch preparation pipeline works on the batches of THREE steps at a time
+  int *u32_c, *it32_c, *perm_c, *hist_c, *btot_c, *bstart_c, *offsets_c, *owner_c, *cnt_c, *stamp_c;
+  int2* perm1_c;
   int64_t total;
 };
 
@@ -109,13 +117,27 @@ struct hsk_ws {
 static inline hsk_ws hsk_select(const hsk_ws& w0, int set, int slot = 0) {
   hsk_ws w = w0;
   if (slot > 0) {   // slot `slot` of both sets' per-batch buffers (grouped preparation)
-    for (int** p : {&w.u32, &w.u32_b}) *p += slot * w.gs_batch;
+    for (int** p : {&w.u32, &w.u32_b}) *p += slot * w.gs_batch;   // (grouped preparation uses sets 0 / 1 only)
     for (int** p : {&w.it32, &w.it32_b, &w.perm, &w.perm_b}) *p += slot * w.gs_ent;
     for (int** p : {&w.offsets, &w.offsets_b}) *p += slot * w.gs_items;
     for (int** p : {&w.owner, &w.owner_b, &w.cnt, &w.cnt_b, &w.stamp, &w.stamp_b}) *p += slot * w.gs_users;
   }
   if (set == 0) return w;
   hsk_ws r = w;
+  if (set == 2) {   // (pipeline only; the lazy-item lists have no third set: the pipeline never runs with lazy items)
+    std::swap(r.u32, r.u32_c);
+    std::swap(r.it32, r.it32_c);
+    std::swap(r.perm1, r.perm1_c);
+    std::swap(r.perm, r.perm_c);
+    std::swap(r.hist, r.hist_c);
+    std::swap(r.btot, r.btot_c);
+    std::swap(r.bstart, r.bstart_c);
+    std::swap(r.offsets, r.offsets_c);
+    std::swap(r.owner, r.owner_c);
+    std::swap(r.cnt, r.cnt_c);
+    std::swap(r.stamp, r.stamp_c);
+    return r;
+  }
   std::swap(r.u32, r.u32_b);
   std::swap(r.it32, r.it32_b);
   std::swap(r.perm1, r.perm1_b);
@@ -195,6 +217,18 @@ static hsk_ws hsk_carve(void* base, int64_t n_users, int64_t n_items, int64_t di
   w.offsets_b = (int*)take(G * (n_items + 1) * 4);
   w.owner_b = (int*)take(G * n_users * 4);
   w.cnt_b = (int*)take(G * n_users * 4);
+  const int64_t c3 = sharded ? 0 : 1;   // third set: one batch (no grouped slots), not carved for the sharded step
+  w.u32_c = (int*)take(c3 * max_batch * 4);
+  w.it32_c = (int*)take(c3 * ent * 4);
+  w.perm1_c = (int2*)take(c3 * ent * 8);
+  w.perm_c = (int*)take(c3 * ent * 4);
+  w.hist_c = (int*)take(c3 * (hist_elems > 0 ? hist_elems : 4) * 4);
+  w.btot_c = (int*)take(c3 * HSK_SORT_MAX_BUCKETS * 4);
+  w.bstart_c = (int*)take(c3 * (HSK_SORT_MAX_BUCKETS + 1) * 4);
+  w.offsets_c = (int*)take(c3 * (n_items + 1) * 4);
+  w.owner_c = (int*)take(c3 * n_users * 4);
+  w.cnt_c = (int*)take(c3 * n_users * 4);
+  w.stamp_c = (int*)take(c3 * n_users * 4);
   w.total = off;
   return w;
 }
@@ -277,6 +311,7 @@ static int hsk_check_state(const hsk_bprmf_state* st) {
 }
 
 static void hsk_aux_drop_graphs(void* aux);   // (defined with struct hsk_aux below)
+static void hsk_aux_forget_pipeline(void* aux);
 
 extern "C" int hsk_bprmf_init_workspace(hsk_bprmf_state* st, hsk_stream_t stream_) {
   HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
@@ -293,6 +328,9 @@ extern "C" int hsk_bprmf_init_workspace(hsk_bprmf_state* st, hsk_stream_t stream
     HSK_HIP(hipMemsetAsync(w.stamp, 0, GU * 4, stream));
     HSK_HIP(hipMemsetAsync(w.stamp_b, 0, GU * 4, stream));
     HSK_HIP(hipMemsetAsync(w.claim, 0, st->n_users * 4, stream));
+    HSK_HIP(hipMemsetAsync(w.stamp_c, 0, st->n_users * 4, stream));
+    HSK_HIP(hipMemsetAsync(w.cnt_c, 0, st->n_users * 4, stream));
+    k_fill_i32<<<(unsigned)hsk_ceil_div(st->n_users, 256), 256, 0, stream>>>(w.owner_c, st->n_users, HSK_OWNER_NONE);
   }
   HSK_HIP(hipMemsetAsync(w.n_touched, 0, 4, stream));
   HSK_HIP(hipMemsetAsync(w.n_touched_b, 0, 4, stream));
@@ -323,6 +361,7 @@ extern "C" int hsk_bprmf_init_workspace(hsk_bprmf_state* st, hsk_stream_t stream
   st->frozen_opt = st->opt_kind;
   st->frozen_valid = 1;
   hsk_aux_drop_graphs(st->aux);   // graphs captured for the previous hyper-parameters are stale
+  hsk_aux_forget_pipeline(st->aux);   // (the owner maps were just re-initialised: nothing to give back)
   return HSK_OK;
 }
 
@@ -432,13 +471,35 @@ struct hsk_aux {
   std::vector<graph_entry> graphs;
   bool graph_broken = false;   // a capture failed once: stay with eager launches
   int64_t graph_launches = 0;  // replayed runs so far (hsk_bprmf_graph_replays)
+  // in-launch preparation pipeline (hsk_pipe_*, below): the batches of the current and of the next two steps, one buffer
+  // set each; `stage` = the preparation phases already done (or enqueued) for the batch in the slot
+  struct pipe_slot {
+    bool valid = false;
+    const int64_t* order = nullptr;
+    int64_t start = 0, batch = 0, n_neg = 0;
+    int64_t step = 0;   // the batch is trained on when st->step == step (its RNG stream id)
+    int stage = 0;      // HSK_PIPE_*
+  } pipe[3];
+  bool pipe_active = false;                 // a pipelined step is being issued: hsk_run_step forks no prefetch of its own
+  const hsk_ride_fwd* ride_fwd = nullptr;   // what rides in the two launches of that step
+  const hsk_ride_item* ride_item = nullptr;
+  int64_t tail_count = 0;                   // consecutive batches the caller named behind the next run (tail_*)
+  int64_t pipe_steps = 0;                   // steps issued through the pipeline so far (debug / tests)
 };
+enum { HSK_PIPE_NONE = 0, HSK_PIPE_S = 1, HSK_PIPE_H = 2, HSK_PIPE_R = 3, HSK_PIPE_C = 4, HSK_PIPE_B = 5 };
 
 static void hsk_aux_drop_graphs(void* a_) {
   hsk_aux* a = (hsk_aux*)a_;
   if (!a) return;
   for (auto& g : a->graphs) (void)hipGraphExecDestroy(g.exec);
   a->graphs.clear();
+}
+
+static void hsk_aux_forget_pipeline(void* a_) {
+  hsk_aux* a = (hsk_aux*)a_;
+  if (!a) return;
+  for (auto& b : a->pipe) b = hsk_aux::pipe_slot{};
+  if (a->cur_set > 1) a->cur_set = 0;
 }
 
 extern "C" void hsk_aux_destroy(void* a_) {
@@ -495,21 +556,29 @@ extern "C" int hsk_bprmf_hint_next(hsk_bprmf_state* st, const int64_t* order, in
   return HSK_OK;
 }
 
-extern "C" int hsk_bprmf_hint_after_run(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
-                                        int64_t n_neg) {
+extern "C" int hsk_bprmf_hint_after_run_n(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
+                                          int64_t n_neg, int64_t n_batches) {
   HSK_REQUIRE(st != nullptr, HSK_ERR_INVALID, "state is NULL");
   hsk_aux* a = (hsk_aux*)st->aux;
   HSK_REQUIRE(a != nullptr, HSK_ERR_INVALID, "hint_after_run needs an aux handle in the state");
   a->tail_valid = false;
-  if (batch <= 0) return HSK_OK;
-  HSK_REQUIRE(batch <= st->max_batch && n_neg >= 1 && n_neg + 1 <= st->max_cols && start >= 0 && start + batch <= st->nnz,
-              HSK_ERR_INVALID, "hint_after_run: batch outside the workspace limits / the interactions");
+  a->tail_count = 0;
+  if (batch <= 0 || n_batches <= 0) return HSK_OK;
+  HSK_REQUIRE(batch <= st->max_batch && n_neg >= 1 && n_neg + 1 <= st->max_cols && start >= 0 &&
+                  start + n_batches * batch <= st->nnz,
+              HSK_ERR_INVALID, "hint_after_run: batches outside the workspace limits / the interactions");
   a->tail_valid = true;
   a->tail_order = order;
   a->tail_start = start;
   a->tail_batch = batch;
   a->tail_nneg = n_neg;
+  a->tail_count = n_batches;
   return HSK_OK;
+}
+
+extern "C" int hsk_bprmf_hint_after_run(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch,
+                                        int64_t n_neg) {
+  return hsk_bprmf_hint_after_run_n(st, order, start, batch, n_neg, 1);
 }
 
 // =============================================================================================
@@ -566,14 +635,16 @@ extern "C" int32_t hsk_bprmf_flush_cadence(const hsk_bprmf_state* st, int32_t ta
 // launch sequence
 // =============================================================================================
 // which: bit 0 = user table, bit 1 = item table (only the lazily updated ones are swept)
-static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream, int which = 3) {
+// g_poison: sharded step only (hsk_guard_skip) -- a run that skipped a step for a capacity overflow sweeps nothing
+static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream, int which = 3,
+                            const int* g_poison = nullptr) {
   const int U = (int)st->n_users, D = (int)st->dim;
   if (st->step == 0) return HSK_OK;
   const hsk_adamw_consts c = hsk_make_adamw_consts(st->lr, st->beta1, st->beta2, st->eps, st->wd, st->step, st->opt_kind);
 #define HSK_FLUSH(VV, GEN)                                                                                       \
   k_user_flush<VV, GEN><<<(unsigned)U, 256, 0, stream>>>(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, \
                                                          st->m_user_bias, st->v_user_bias, w.last_step, U, D,         \
-                                                         (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN)
+                                                         (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN, g_poison)
   const bool gen = st->opt_kind != HSK_OPT_ADAMW;
   if (st->lazy_users && (which & 1)) {
     if (D % 2 == 0) {
@@ -588,11 +659,11 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
     if (gen)
       k_user_flush<2, true><<<(unsigned)I, 256, 0, stream>>>(st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias,
                                                             st->m_item_bias, st->v_item_bias, w.last_step_i, I, D,
-                                                            (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN);
+                                                            (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN, g_poison);
     else
       k_user_flush<2, false><<<(unsigned)I, 256, 0, stream>>>(st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias,
                                                              st->m_item_bias, st->v_item_bias, w.last_step_i, I, D,
-                                                             (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN);
+                                                             (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN, g_poison);
   }
   HSK_LAUNCH_CHECK();
   return HSK_OK;
@@ -600,7 +671,7 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
 
 // the periodic sweeps due after the steps (step_before, st->step]; user_rows / entries: what one step touches
 static int hsk_periodic_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t stream, int64_t step_before,
-                              double user_rows, double entries) {
+                              double user_rows, double entries, const int* g_poison = nullptr) {
   int which = 0;
   if (st->lazy_users) {
     const int64_t F = hsk_flush_cadence(st, 0, user_rows);
@@ -612,7 +683,7 @@ static int hsk_periodic_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t 
   }
   if (!which) return HSK_OK;
   int rc = HSK_OK;
-  HSK_STAGE(HSK_STAGE_USER, rc = hsk_launch_flush(st, w, stream, which));
+  HSK_STAGE(HSK_STAGE_USER, rc = hsk_launch_flush(st, w, stream, which, g_poison));
   return rc;
 }
 
@@ -625,13 +696,15 @@ template <int V, int NCH, bool FULL, int R, bool APPLY>
 static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, const float* Urows, const int* urow_index,
                                  int K, const hsk_adamw_consts& c, float* gI_out, float* gIb_out, hipStream_t stream,
                                  int64_t n_entries = 0, const hsk_user_lazy_args* ua = nullptr,
-                                 const hsk_ahead_args* aa = nullptr, int n_part = 1) {
+                                 const hsk_ahead_args* aa = nullptr, int n_part = 1, const int* g_ovf = nullptr,
+                                 const int* g_poison = nullptr, const hsk_ride_item* ri = nullptr) {
+  // g_ovf / g_poison: the sharded step's overflow guard (hsk_guard_skip); its item pass never carries `ua`
   const bool part = n_part > 1;
   const int I = (int)st->n_items, D = (int)st->dim;
   if (D % 2 != 0) {
     k_item_update<V, NCH, FULL, R, APPLY><<<(unsigned)hsk_ceil_div(I, 4), 256, 0, stream>>>(
         Urows, st->item_emb, st->item_bias, st->m_item_emb, st->v_item_emb, st->m_item_bias, st->v_item_bias,
-        urow_index, w.g_s, w.perm, w.offsets, I, K, D, c, gI_out, gIb_out);
+        urow_index, w.g_s, w.perm, w.offsets, I, K, D, c, gI_out, gIb_out, g_ovf, g_poison);
     return;
   }
   // slice width: 64 lanes x VS floats, the widest vector the row alignment allows (narrower slices and more items per
@@ -677,8 +750,9 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
           ia, *ua, nub, dense, ahead, n_ahead_oct, stride);                                                    \
     else if (part) {                                                                                           \
       if constexpr (V == 4 && FULL && !LZ)                                                                      \
-        k_item_user<V, NCH, FULL, VS, GEN, LZ, true><<<nblk + (unsigned)nub, 256, 0, stream>>>(ia, *ua, nub, dense, \
-                                                                                            ahead, 0);         \
+        k_item_user<V, NCH, FULL, VS, GEN, LZ, true><<<nblk + (unsigned)nub + (unsigned)(ri ? ri->n_total : 0), 256, 0, \
+                                                       stream>>>(ia, *ua, nub, dense, ahead, 0,                \
+                                                                 ri ? *ri : hsk_ride_item{});                  \
     } else                                                                                                     \
       k_item_user<V, NCH, FULL, VS, GEN, LZ><<<nblk + (unsigned)(nub + (LZ ? nab_big : 0)), 256, 0, stream>>>(   \
           ia, *ua, nub, dense, ahead, LZ ? nab_big : 0);                                                       \
@@ -697,8 +771,8 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
     hsk_item_args ir = ia;
     ir.n_slices_pad = 0;
     if constexpr (APPLY) {
-      if (gen) k_item_update_rows<V, NCH, FULL, true, true><<<nb, 256, 0, stream>>>(ir);
-      else     k_item_update_rows<V, NCH, FULL, false, true><<<nb, 256, 0, stream>>>(ir);
+      if (gen) k_item_update_rows<V, NCH, FULL, true, true><<<nb, 256, 0, stream>>>(ir, g_ovf, g_poison);
+      else     k_item_update_rows<V, NCH, FULL, false, true><<<nb, 256, 0, stream>>>(ir, g_ovf, g_poison);
     }
     return;
   }
@@ -706,9 +780,9 @@ static void hsk_launch_item_pass(const hsk_bprmf_state* st, const hsk_ws& w, con
   do {                                                                                 \
     if (part) {                                                                        \
       if constexpr (APPLY && V == 4 && FULL && !LZ)                                    \
-        k_item_update_sliced<APPLY, VS, GEN, LZ, true><<<nblk, 256, 0, stream>>>(ia);   \
+        k_item_update_sliced<APPLY, VS, GEN, LZ, true><<<nblk, 256, 0, stream>>>(ia, g_ovf, g_poison);   \
     } else                                                                             \
-      k_item_update_sliced<APPLY, VS, GEN, LZ><<<nblk, 256, 0, stream>>>(ia);          \
+      k_item_update_sliced<APPLY, VS, GEN, LZ><<<nblk, 256, 0, stream>>>(ia, g_ovf, g_poison);          \
   } while (0)
   if (gen) { if (lazy) HSK_ITEM_SLICED(VSC, true, true); else HSK_ITEM_SLICED(VSC, true, false); }
   else     { if (lazy) HSK_ITEM_SLICED(VSC, false, true); else HSK_ITEM_SLICED(VSC, false, false); }
@@ -828,6 +902,7 @@ static bool hsk_pf_early(int64_t B) {
 static bool hsk_prefetch_wanted(const hsk_bprmf_state* st) {
   hsk_aux* aux = (hsk_aux*)st->aux;
   if (!aux || !aux->hint_valid) return false;
+  if (aux->pipe_active) return false;   // the preparation rides in the step's own launches (hsk_pipe_step)
   if (aux->grouped) return false; // the run's batches are prepared G at a time by the capture loop (hsk_capture_steps)
   if (aux->g_desc) return true;   // inside a graph the fork / join are dependencies, not host calls
   if (aux->hint_batch * (aux->hint_nneg + 1) < HSK_PREFETCH_MIN_ENTRIES) {
@@ -855,6 +930,10 @@ static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set
     prc = hsk_launch_sort(st, wn, tot, aux->side);
   }
   if (prc) return prc;
+  {   // experiment (HSK_SIDE_DUMMY=n): n empty launches behind the sort -- what a kernel boundary on the side stream costs
+    static const int n_dummy = getenv("HSK_SIDE_DUMMY") ? atoi(getenv("HSK_SIDE_DUMMY")) : 0;
+    for (int i = 0; i < n_dummy && !aux->g_desc; ++i) k_fill_i32<<<1, 64, 0, aux->side>>>(nullptr, 0, 0);
+  }
   HSK_HIP(hipEventRecord(aux->ev_ready, aux->side));
   aux->pf_valid = true;
   aux->pf_order = aux->hint_order;
@@ -977,6 +1056,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       // item-partitioned forward; the NEXT batch's user rows are brought up to date by leading workgroups of the same
       // launch (pure VALU work beside a kernel that waits on the L2 / the fabric), see hsk_fwd_part.h
       if constexpr (V == 4 && FULL) {
+        constexpr int RP = (V * NCH >= 16) ? 2 : HSK_FWD_PART_R;
         hsk_ahead_args aa = {};
         int n_ahead = 0;
         static const int ahead_on = getenv("HSK_AHEAD") ? atoi(getenv("HSK_AHEAD")) : 1;
@@ -993,18 +1073,19 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
         static const int ahead_mix = getenv("HSK_AHEAD_MIX") ? atoi(getenv("HSK_AHEAD_MIX")) : 0;
         const int stride = (ahead_mix && n_ahead > 0) ? (int)(n_unit / 8) / (n_ahead / 8) : 0;
         const hsk_part_args pa = {n_part, (int)st->n_items, n_ahead, stride};
-        const unsigned grid = (unsigned)n_ahead + n_unit;
+        const hsk_ride_fwd rf = (aux && aux->ride_fwd) ? *aux->ride_fwd : hsk_ride_fwd{};   // riding preparation phases
+        const unsigned grid = (unsigned)rf.n_total + (unsigned)n_ahead + n_unit;
 #define HSK_LAUNCH_FWD_PART(LK, GEN)                                                                                 \
   if (capturing)                                                                                                    \
-    hipLaunchKernelGGL((k_fwd_part<V, NCH, FULL, R, LK, GEN>), dim3(grid), dim3(256), 0, stream,                     \
+    hipLaunchKernelGGL((k_fwd_part<V, NCH, FULL, RP, LK, GEN>), dim3(grid), dim3(256), 0, stream,                    \
                        (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,         \
                        (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b, lz,  \
-                       pa, aa);                                                                                     \
+                       pa, aa, rf);                                                                                 \
   else                                                                                                              \
-    hipExtLaunchKernelGGL((k_fwd_part<V, NCH, FULL, R, LK, GEN>), dim3(grid), dim3(256), 0, stream, fwd_beg, fwd_end,  \
+    hipExtLaunchKernelGGL((k_fwd_part<V, NCH, FULL, RP, LK, GEN>), dim3(grid), dim3(256), 0, stream, fwd_beg, fwd_end, \
                           0, (const float*)st->user_emb, (const float*)st->item_emb, (const float*)st->item_bias,   \
                           (const int*)w.u32, (const int*)w.it32, (int)B, (int)K, D, inv_bn, w.g_s, w.dUb, w.loss_b,  \
-                          lz, pa, aa)
+                          lz, pa, aa, rf)
         if (st->loss_kind == HSK_LOSS_BCE) {
           if (gen) { HSK_LAUNCH_FWD_PART(HSK_LOSS_BCE, true); } else { HSK_LAUNCH_FWD_PART(HSK_LOSS_BCE, false); }
         } else {
@@ -1097,7 +1178,7 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
       }
       // the item pass reads the user rows from ucur, the user blocks rewrite the table: independent -> one launch
       hsk_launch_item_pass<V, NCH, FULL, R, true>(st, w, w.ucur, nullptr, (int)K, c, nullptr, nullptr, stream, total, &ua,
-                                                  &aa, n_part);
+                                                  &aa, n_part, nullptr, nullptr, aux ? aux->ride_item : nullptr);
     } else {
       const bool from_ucur = lazy || D % 2 == 0;
       HSK_STAGE(HSK_STAGE_ITEM, (hsk_launch_item_pass<V, NCH, FULL, R, true>(
@@ -1146,6 +1227,228 @@ static int hsk_check_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_c
   return HSK_OK;
 }
 
+// =============================================================================================
+// in-launch preparation pipeline (large batches on the item-partitioned forward)
+// =============================================================================================
+// The side-stream prefetch above costs the step more than the work it overlaps: timelines of the ml10m step
+// (profiles/r4_ml10m) show ~5 us between the forward and the item/user launch (the fork event riding on the forward's
+// completion signal), 8-12 us between the item/user launch and the next forward (the join on the side stream's event),
+// and the item/user launch stretched from 70 to 95 us by five high-priority launches trickling through it -- each empty
+// launch added to that stream costs the step another 2.5 us.  Here the five preparation phases of a batch
+//   S sample   H per-unit bucket histogram   R per-bucket scan over the units   C scatter by bucket   B sort inside buckets
+// run as EXTRA WORKGROUPS AT THE HEAD of the two launches a step has anyway (hsk_ride_fwd / hsk_ride_item), two steps
+// ahead: the forward of step t carries B of batch t, S of batch t+2 and R of batch t+1; its item/user launch C of batch
+// t+1 and H of batch t+2.  The launch boundaries between them are the phases' barriers; there is no side stream, no
+// event and no launch of its own on the step's path.  Three buffer sets rotate.  Same kernels' bodies, same draws, same
+// sort: bit-identical batches, losses and parameters (tests/test_hip_parity.py).
+// What is not prepared when its step comes (the first steps of a run, a batch the caller did not name ahead of time) is
+// brought up to date by stand-alone launches of the same phases on the step's own stream.
+struct hsk_batch_desc {
+  bool valid;
+  const int64_t* order;
+  int64_t start, batch, n_neg, step;
+};
+
+static bool hsk_pipe_plan(const hsk_bprmf_state* st, int64_t batch, int64_t n_neg, int* n_part_out, hsk_sort_plan* plan,
+                          int64_t* total_out) {
+  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0);
+  const int64_t total = batch * hsk_part_cols(n_neg + 1, n_part);
+  if (n_part_out) *n_part_out = n_part;
+  if (total_out) *total_out = total;
+  if (n_part <= 1 || hsk_sort_lds_fits(st->n_items, total) || total <= 1024 * 8) return false;
+  hsk_sort_plan p;
+  if (hsk_make_sort_plan(st->n_items, total, &p) != 0 || p.ipb > HSK_PIPE_MAX_IPB) return false;
+  if (plan) *plan = p;
+  return true;
+}
+
+// HSK_PIPE=0: the side-stream prefetch everywhere (A/B runs, and the reference the bit-equality tests hold the pipeline to)
+static bool hsk_pipe_eligible(const hsk_bprmf_state* st, int64_t batch, int64_t n_neg) {
+  static const int env = getenv("HSK_PIPE") ? atoi(getenv("HSK_PIPE")) : 1;
+  const hsk_aux* a = (const hsk_aux*)st->aux;
+  if (!env || !a || a->g_desc || st->ws_sharded || st->lazy_items) return false;
+  if (st->loss_kind != HSK_LOSS_BPR && st->loss_kind != HSK_LOSS_BCE) return false;
+  if (st->timing && (st->timing_mask & ~(1 << HSK_STAGE_FWD))) return false;   // stage timing brackets the separate launches
+  return hsk_pipe_plan(st, batch, n_neg, nullptr, nullptr, nullptr);
+}
+
+// one phase of the preparation of the batch in `b`, as a launch of its own
+static int hsk_pipe_launch_phase(const hsk_bprmf_state* st, const hsk_ws& w, const hsk_aux::pipe_slot& b, int phase,
+                                 hipStream_t stream) {
+  hsk_sort_plan plan;
+  int64_t total = 0;
+  HSK_REQUIRE(hsk_pipe_plan(st, b.batch, b.n_neg, nullptr, &plan, &total), HSK_ERR_UNSUPPORTED, "internal: pipeline shape");
+  const int I = (int)st->n_items;
+  switch (phase) {
+    case HSK_PIPE_S:
+      return hsk_launch_prep_sample(st, w, b.order, b.start, b.batch, b.n_neg, (uint64_t)b.step, stream);
+    case HSK_PIPE_H:
+      k_sort_hist<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist, nullptr);
+      break;
+    case HSK_PIPE_R:
+      k_sort_rowscan<<<(unsigned)hsk_ceil_div(plan.n_buckets, 4), 256, 0, stream>>>(w.hist, plan, w.btot);
+      break;
+    case HSK_PIPE_C:
+      k_sort_scatter<<<(unsigned)hsk_ceil_div(plan.n_units, 4), 256, 0, stream>>>(w.it32, (int)total, plan, w.hist, w.btot,
+                                                                                   w.perm1, w.bstart, nullptr);
+      break;
+    default:
+      k_sort_bucket<<<(unsigned)plan.n_buckets, 256, (5 * (size_t)plan.ipb + 2) * sizeof(int), stream>>>(
+          w.perm1, (int)total, I, plan, w.bstart, w.perm, w.offsets, nullptr, nullptr, nullptr);
+  }
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
+static hsk_ride_sort hsk_pipe_ride_sort(const hsk_bprmf_state* st, const hsk_ws& w, const hsk_aux::pipe_slot& b, int phase) {
+  hsk_sort_plan plan;
+  int64_t total = 0;
+  (void)hsk_pipe_plan(st, b.batch, b.n_neg, nullptr, &plan, &total);
+  const int n_blocks = phase == HSK_PIPE_B ? plan.n_buckets
+                                           : (int)hsk_ceil_div(phase == HSK_PIPE_R ? plan.n_buckets : plan.n_units, 4);
+  return hsk_ride_sort{n_blocks, w.it32, (int)total, (int)st->n_items, plan, w.hist, w.btot, w.perm1, w.bstart, w.perm, w.offsets};
+}
+
+// give the owner map of a sampled batch that will not be trained on back, forget the slot
+static int hsk_pipe_drop(hsk_bprmf_state* st, const hsk_ws& w_all, int slot, hipStream_t stream) {
+  hsk_aux* a = (hsk_aux*)st->aux;
+  hsk_aux::pipe_slot& b = a->pipe[slot];
+  if (b.valid && b.stage >= HSK_PIPE_S) {
+    const hsk_ws w = hsk_select(w_all, slot);
+    k_release_owner<<<(unsigned)hsk_ceil_div(b.batch, 256), 256, 0, stream>>>(w.u32, (int)b.batch, w.owner, w.cnt);
+    HSK_LAUNCH_CHECK();
+  }
+  b = hsk_aux::pipe_slot{};
+  return HSK_OK;
+}
+
+// leaves the pipeline empty (a flush, a step issued through another path, a re-initialised workspace)
+static int hsk_pipe_reset(hsk_bprmf_state* st, const hsk_ws& w_all, hipStream_t stream) {
+  hsk_aux* a = (hsk_aux*)st->aux;
+  if (!a) return HSK_OK;
+  for (int i = 0; i < 3; ++i) {
+    int rc = hsk_pipe_drop(st, w_all, i, stream);
+    if (rc) return rc;
+  }
+  if (a->cur_set > 1) a->cur_set = 0;   // (the other paths alternate between sets 0 and 1; the sets are scratch)
+  return HSK_OK;
+}
+
+static bool hsk_pipe_same(const hsk_aux::pipe_slot& b, const hsk_batch_desc& d) {
+  return b.valid && d.valid && b.order == d.order && b.start == d.start && b.batch == d.batch && b.n_neg == d.n_neg &&
+         b.step == d.step;
+}
+
+// ONE step of a pipelined run: `cur` is trained on now (cur.step == st->step); n1 / n2 are the batches of the next two
+// steps where the caller knows them.
+static int hsk_pipe_step(hsk_bprmf_state* st, const hsk_ws& w_all, const hsk_batch_desc& cur, const hsk_batch_desc& n1,
+                         const hsk_batch_desc& n2, hipStream_t stream) {
+  hsk_aux* a = (hsk_aux*)st->aux;
+  int n_part = 1;
+  HSK_REQUIRE(hsk_pipe_plan(st, cur.batch, cur.n_neg, &n_part, nullptr, nullptr), HSK_ERR_UNSUPPORTED, "internal: pipeline shape");
+  // slots: keep what matches, drop what does not (a wrong guess, a stale run), hand the free ones out
+  const hsk_batch_desc* want[3] = {&cur, &n1, &n2};
+  int slot_of[3] = {-1, -1, -1};
+  bool used[3] = {false, false, false};
+  for (int k = 0; k < 3; ++k)
+    for (int i = 0; i < 3 && slot_of[k] < 0; ++i)
+      if (!used[i] && hsk_pipe_same(a->pipe[i], *want[k])) {
+        slot_of[k] = i;
+        used[i] = true;
+      }
+  int rc;
+  for (int i = 0; i < 3; ++i)
+    if (!used[i] && a->pipe[i].valid && (rc = hsk_pipe_drop(st, w_all, i, stream))) return rc;
+  for (int k = 0; k < 3; ++k) {
+    if (!want[k]->valid || slot_of[k] >= 0) continue;
+    for (int i = 0; i < 3 && slot_of[k] < 0; ++i)
+      if (!used[i]) {
+        slot_of[k] = i;
+        used[i] = true;
+        a->pipe[i] = hsk_aux::pipe_slot{true, want[k]->order, want[k]->start, want[k]->batch, want[k]->n_neg, want[k]->step,
+                                        HSK_PIPE_NONE};
+      }
+  }
+  // HSK_PIPE_ALONE=1 (experiments): nothing rides -- every phase of the step's batch as a launch of its own in front of it
+  // (a timeline then shows the forward, the item/user launch and the five phases each by itself)
+  static const int alone = getenv("HSK_PIPE_ALONE") ? atoi(getenv("HSK_PIPE_ALONE")) : 0;
+  const int sc = slot_of[0], s1 = alone ? -1 : slot_of[1], s2 = alone ? -1 : slot_of[2];
+  if (alone) {
+    const hsk_ws w = hsk_select(w_all, sc);
+    while (a->pipe[sc].stage < HSK_PIPE_B) {
+      if ((rc = hsk_pipe_launch_phase(st, w, a->pipe[sc], a->pipe[sc].stage + 1, stream))) return rc;
+      a->pipe[sc].stage += 1;
+    }
+  }
+  // what should have ridden in earlier steps and did not (cold start): on this stream, now
+  for (int k = 0; k < 2; ++k) {
+    const int sl = k == 0 ? sc : s1;
+    if (sl < 0) continue;
+    const int need = k == 0 ? HSK_PIPE_C : HSK_PIPE_H;
+    const hsk_ws w = hsk_select(w_all, sl);
+    while (a->pipe[sl].stage < need) {
+      if ((rc = hsk_pipe_launch_phase(st, w, a->pipe[sl], a->pipe[sl].stage + 1, stream))) return rc;
+      a->pipe[sl].stage += 1;
+    }
+  }
+  // what rides in this step's two launches
+  hsk_ride_fwd rf = {};
+  hsk_ride_item ri = {};
+  {
+    const hsk_ws wc = hsk_select(w_all, sc);
+    if (a->pipe[sc].stage == HSK_PIPE_C) {
+      rf.Bk = hsk_pipe_ride_sort(st, wc, a->pipe[sc], HSK_PIPE_B);
+      a->pipe[sc].stage = HSK_PIPE_B;
+    }
+  }
+  if (s1 >= 0) {
+    const hsk_ws w1 = hsk_select(w_all, s1);
+    if (a->pipe[s1].stage == HSK_PIPE_H) {
+      rf.R = hsk_pipe_ride_sort(st, w1, a->pipe[s1], HSK_PIPE_R);
+      a->pipe[s1].stage = HSK_PIPE_R;
+    }
+    if (a->pipe[s1].stage == HSK_PIPE_R) {
+      ri.C = hsk_pipe_ride_sort(st, w1, a->pipe[s1], HSK_PIPE_C);
+      a->pipe[s1].stage = HSK_PIPE_C;
+    }
+  }
+  if (s2 >= 0) {
+    const hsk_ws w2 = hsk_select(w_all, s2);
+    const hsk_aux::pipe_slot& b = a->pipe[s2];
+    if (b.stage == HSK_PIPE_NONE) {
+      rf.S = hsk_ride_sample{(int)hsk_ceil_div(b.batch, 4), st->coo_user, st->coo_item, b.order, (long long)b.start,
+                             (int)b.batch, (int)b.n_neg, st->csr_indptr, st->csr_indices, (int)st->n_items, st->seed,
+                             (uint64_t)b.step, w2.u32, w2.it32, w2.owner, w2.cnt, st->status,
+                             hsk_alias{st->alias_prob, st->alias_idx}, w2.stamp, n_part};
+      a->pipe[s2].stage = HSK_PIPE_S;
+    }
+    if (a->pipe[s2].stage == HSK_PIPE_S) {
+      ri.H = hsk_pipe_ride_sort(st, w2, a->pipe[s2], HSK_PIPE_H);
+      a->pipe[s2].stage = HSK_PIPE_H;
+    }
+  }
+  rf.n_total = (int)hsk_align_up(rf.Bk.n_blocks + rf.S.n_blocks + rf.R.n_blocks, 8);
+  ri.n_total = (int)hsk_align_up(ri.C.n_blocks + ri.H.n_blocks, 8);
+  // the ahead-of-time replay of the next batch's lazily updated user rows takes the next batch from the hint
+  a->pf_valid = false;
+  a->hint_valid = n1.valid;
+  a->hint_order = n1.order;
+  a->hint_start = n1.start;
+  a->hint_batch = n1.batch;
+  a->hint_nneg = n1.n_neg;
+  a->pipe_active = true;
+  a->ride_fwd = &rf;
+  a->ride_item = &ri;
+  rc = hsk_run_step(st, w_all, sc, true, cur.batch, cur.n_neg + 1, stream, n_part);
+  a->pipe_active = false;
+  a->ride_fwd = nullptr;
+  a->ride_item = nullptr;
+  a->hint_valid = false;
+  a->pipe[sc] = hsk_aux::pipe_slot{};   // trained on: its owner map was given back by the user update
+  a->pipe_steps += 1;
+  return rc;
+}
+
 extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, const int64_t* i_idx, int64_t batch,
                                     int64_t n_cols, hsk_stream_t stream_) {
   int rc = hsk_check_state(st);
@@ -1156,6 +1459,7 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   hsk_ws w = hsk_carve_st(st);
   const int64_t total = batch * n_cols;
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
+  if ((rc = hsk_pipe_reset(st, w, stream))) return rc;
   if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
   const int set = st->aux ? (((hsk_aux*)st->aux)->cur_set ^ 1) : 0;
   const hsk_ws ws = hsk_select(w, set);
@@ -1182,6 +1486,7 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
   hsk_aux* aux = (hsk_aux*)st->aux;
   const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0);
+  if ((rc = hsk_pipe_reset(st, w, stream))) return rc;
   if (aux && aux->pf_valid && aux->pf_order == order && aux->pf_start == start && aux->pf_batch == batch &&
       aux->pf_nneg == n_neg && aux->pf_step == st->step) {
     // this batch was sampled and sorted on the side stream during the previous step
@@ -1222,6 +1527,7 @@ __global__ void k_set_desc(hsk_step_desc* d, long long start0, const int64_t* or
 // timing fields may differ between capture and replay (the former is read from the device descriptor).  A caller that
 // changes anything else between two hsk_bprmf_train_steps calls -- an LR schedule through st->lr, parameters rebound
 // after .to(), a new dataset -- gets a fresh capture, exactly as the eager path would pick the new values up.
+static_assert(sizeof(hsk_bprmf_state) == 424, "hsk_bprmf_state has no padding holes: its byte image is a valid key");
 static hsk_bprmf_state hsk_graph_key(const hsk_bprmf_state* st) {
   hsk_bprmf_state k;
   memcpy(&k, st, sizeof(k));
@@ -1371,6 +1677,38 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
               "steps [%lld, +%lld x %lld) outside nnz %lld", (long long)start, (long long)n_steps, (long long)batch,
               (long long)st->nnz);
   int64_t s = 0;
+  if (st->aux && n_steps > 0 && hsk_pipe_eligible(st, batch, n_neg)) {
+    // large batches on the item-partitioned forward: the preparation of the next two batches rides in the steps' own
+    // launches (hsk_pipe_step); the batches behind the run come from hsk_bprmf_hint_after_run[_n]
+    int rc = hsk_check_state(st);
+    if (rc) return rc;
+    HSK_REQUIRE(st->csr_indptr && st->csr_indices && st->coo_user && st->coo_item, HSK_ERR_INVALID,
+                "CSR/COO of the training interactions missing from the state");
+    if ((rc = hsk_check_batch(st, batch, n_neg + 1))) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    hsk_aux* aux = (hsk_aux*)st->aux;
+    const hsk_ws w = hsk_carve_st(st);
+    if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
+    aux->hint_valid = false;
+    const bool tail_ok = aux->tail_valid && aux->tail_batch == batch && aux->tail_nneg == n_neg;
+    auto desc = [&](int64_t k) -> hsk_batch_desc {   // the batch trained on k steps from the start of this run
+      if (k < n_steps) return hsk_batch_desc{true, order, start + k * batch, batch, n_neg, 0};
+      const int64_t j = k - n_steps;
+      if (tail_ok && j < aux->tail_count) return hsk_batch_desc{true, aux->tail_order, aux->tail_start + j * batch, batch, n_neg, 0};
+      return hsk_batch_desc{false, nullptr, 0, 0, 0, 0};
+    };
+    for (; s < n_steps; ++s) {
+      hsk_batch_desc cur = desc(s), n1 = desc(s + 1), n2 = desc(s + 2);
+      cur.step = st->step;
+      n1.step = st->step + 1;
+      n2.step = st->step + 2;
+      st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
+      if ((rc = hsk_pipe_step(st, w, cur, n1, n2, stream))) return rc;
+    }
+    aux->tail_valid = false;
+    aux->tail_count = 0;
+    return HSK_OK;
+  }
   const int64_t chunk_max = hsk_graph_chunk(st);
   if (chunk_max >= 2 && n_steps >= chunk_max) {
     int rc = hsk_check_state(st);
@@ -1454,6 +1792,11 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
   return HSK_OK;
 }
 
+extern "C" int64_t hsk_bprmf_pipelined_steps(const hsk_bprmf_state* st) {
+  const hsk_aux* a = st ? (const hsk_aux*)st->aux : nullptr;
+  return a ? a->pipe_steps : 0;
+}
+
 extern "C" int64_t hsk_bprmf_graph_replays(const hsk_bprmf_state* st) {
   const hsk_aux* a = st ? (const hsk_aux*)st->aux : nullptr;
   return a ? a->graph_launches : 0;
@@ -1468,6 +1811,7 @@ extern "C" int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream_) {
   if (st->aux) {
     ((hsk_aux*)st->aux)->hint_valid = false;
     if ((rc = hsk_discard_prefetch(st, w, (hipStream_t)stream_))) return rc;
+    if ((rc = hsk_pipe_reset(st, w, (hipStream_t)stream_))) return rc;
   }
   if (!st->lazy_users && !st->lazy_items) return HSK_OK;  // dense updates: nothing is pending
   return hsk_launch_flush(st, w, (hipStream_t)stream_);

@@ -21,7 +21,27 @@
 // the rows current; a row that is behind all the same (no hint, first step) is replayed in registers by each of its P
 // units, unit 0 publishes it -- correct, just P times the arithmetic for that row.
 #pragma once
+#include "hsk_sampler.h"
+#include "hsk_sort.h"
 #include "hsk_step_kernels.h"
+
+// In-launch preparation pipeline (hsk_fused.hip: hsk_pipe_*): phases of the batches one and two steps ahead ride in
+// the step's two launches as extra workgroups at the head of the grid, instead of five launches on a side stream --
+// no cross-stream events on the step's path, and the launch boundaries the step has anyway are the phases' barriers.
+//   forward of step t     bucket phase of batch t, sampler of batch t+2, row scan of batch t+1
+//   item/user launch of t scatter of batch t+1, histogram of batch t+2
+// n_total = the riding workgroups padded to a multiple of 8 (the workgroups behind keep index % 8 == their own index % 8).
+struct hsk_ride_fwd {
+  int n_total;
+  hsk_ride_sort Bk;
+  hsk_ride_sample S;
+  hsk_ride_sort R;
+};
+struct hsk_ride_item {
+  int n_total;
+  hsk_ride_sort C;
+  hsk_ride_sort H;
+};
 
 struct hsk_part_args {
   int n_part;                    // P: 2, 4 or 8; partition q = items [ceil(q I / P), ceil((q + 1) I / P))
@@ -33,15 +53,39 @@ struct hsk_part_args {
 };
 #define HSK_PART_LIST_MAX 256    // negatives per positive (the partition rule keeps n_neg <= 256)
 
+// The riding phases of the forward's launch.  (Any of them in the kernel costs the gather loop's register allocation one
+// register: 129 with four item rows per buffer -- three waves per SIMD; capped at 128 it spills and the kernel runs 86 ->
+// 96 us; called out of line it needs a stack.  Hence HSK_FWD_PART_R = 3 rows per buffer: 114 registers.)
+__device__ __forceinline__ void hsk_ride_fwd_roles(const hsk_ride_fwd& rf, int bid) {
+  if (bid < rf.Bk.n_blocks) {
+    __shared__ int bucket_lds[5 * HSK_PIPE_MAX_IPB + 2];
+    hsk_sort_bucket_body(rf.Bk.perm1, rf.Bk.n_entries, rf.Bk.n_items, rf.Bk.plan, rf.Bk.bstart, rf.Bk.perm, rf.Bk.offsets,
+                         nullptr, nullptr, bid, bucket_lds);
+    return;
+  }
+  bid -= rf.Bk.n_blocks;
+  if (bid < rf.S.n_blocks) {
+    hsk_ride_sample_body(rf.S, bid);
+    return;
+  }
+  bid -= rf.S.n_blocks;
+  if (bid < rf.R.n_blocks) hsk_sort_rowscan_body(rf.R.hist, rf.R.plan, rf.R.btot, bid);
+}
+
 template <int V, int NCH, bool FULL, int R, int LOSS, bool GEN>
 __global__ __launch_bounds__(256) void k_fwd_part(const float* __restrict__ Uw, const float* __restrict__ Iw,
                                                   const float* __restrict__ Ib, const int* __restrict__ u32,
                                                   const int* __restrict__ it32, int B, int K /* columns */, int D, float inv_norm,
                                                   float* __restrict__ g_s, float* __restrict__ dUp,
                                                   double* __restrict__ loss_p, hsk_lazy_user_args lz, hsk_part_args pa,
-                                                  hsk_ahead_args aa) {
+                                                  hsk_ahead_args aa, hsk_ride_fwd rf) {
   static_assert(LOSS == HSK_LOSS_BPR || LOSS == HSK_LOSS_BCE, "the sampled softmax needs all negatives in one wave");
   int bid = (int)blockIdx.x;
+  if (bid < rf.n_total) {   // preparation phases of later batches (see hsk_ride_fwd)
+    hsk_ride_fwd_roles(rf, bid);
+    return;
+  }
+  bid -= rf.n_total;
   if (pa.ahead_stride > 0) {
     const int o = bid >> 3, r = bid & 7, n_ao = pa.n_ahead_blocks >> 3;
     const int period = pa.ahead_stride + 1, full = n_ao * period;

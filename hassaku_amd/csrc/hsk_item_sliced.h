@@ -10,6 +10,7 @@
 #pragma once
 #include "hsk_rows.h"
 #include "hsk_step_kernels.h"
+#include "hsk_fwd_part.h"
 
 #ifndef HSK_ITEM_MLP
 // user-row loads a wave keeps in flight.  4: with 8 the kernel sat on its 64-VGPR budget (8 waves per SIMD) with spills
@@ -282,13 +283,17 @@ __device__ __forceinline__ void hsk_item_row_body(const hsk_item_args& a, int bi
 }
 
 template <bool APPLY, int VS, bool GEN, bool LAZY = false, bool PART = false>
-__global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a) {
+__global__ __launch_bounds__(256) void k_item_update_sliced(hsk_item_args a, const int* __restrict__ g_ovf = nullptr,
+                                                            const int* __restrict__ g_poison = nullptr) {
+  if (APPLY && hsk_guard_skip(g_ovf, g_poison)) return;   // sharded step: see hsk_guard_skip
   hsk_item_sliced_body<APPLY, VS, GEN, LAZY, PART>(a, (int)blockIdx.x);
 }
 
 // whole rows as a launch of their own: the sharded step's item pass over the TOUCHED rows of a shard (lazy item AdamW)
 template <int V, int NCH, bool FULL, bool GEN, bool LAZY>
-__global__ __launch_bounds__(256) void k_item_update_rows(hsk_item_args a) {
+__global__ __launch_bounds__(256) void k_item_update_rows(hsk_item_args a, const int* __restrict__ g_ovf = nullptr,
+                                                          const int* __restrict__ g_poison = nullptr) {
+  if (hsk_guard_skip(g_ovf, g_poison)) return;   // sharded step: see hsk_guard_skip
   hsk_item_row_body<V, NCH, FULL, GEN, LAZY>(a, (int)blockIdx.x);
 }
 
@@ -311,8 +316,20 @@ __global__ __launch_bounds__(256) void k_item_update_rows(hsk_item_args a) {
 template <int V, int NCH, bool FULL, int VS, bool GEN, bool LAZYI, bool PART = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_item_user(hsk_item_args ia, hsk_user_lazy_args ua, int n_user_blocks, int dense_users, hsk_ahead_args aa,
-                 int n_ahead_blocks) {
-  const int bid = (int)blockIdx.x;
+                 int n_ahead_blocks, hsk_ride_item ri = hsk_ride_item{}) {
+  int bid = (int)blockIdx.x;
+  if (PART) {   // preparation phases of later batches riding in this launch (hsk_fwd_part.h: hsk_ride_item)
+    if (bid < ri.n_total) {
+      __shared__ int ride_lds[HSK_SORT_SCATTER_LDS];
+      if (bid < ri.C.n_blocks) {
+        hsk_sort_scatter_body(ri.C.it32, ri.C.n_entries, ri.C.plan, ri.C.hist, ri.C.btot, ri.C.perm1, ri.C.bstart, bid, ride_lds);
+      } else if (bid - ri.C.n_blocks < ri.H.n_blocks) {
+        hsk_sort_hist_body(ri.H.it32, ri.H.n_entries, ri.H.plan, ri.H.hist, bid - ri.C.n_blocks, ride_lds);
+      }
+      return;
+    }
+    bid -= ri.n_total;
+  }
   if (bid < n_user_blocks) {
     if (dense_users)
       hsk_user_update_dense_body<V, NCH, FULL, GEN, PART>(ua, bid);

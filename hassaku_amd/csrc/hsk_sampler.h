@@ -180,6 +180,35 @@ __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__
                        stream_id, u32, it32, owner, cnt, status, b_offset, at, stamp, n_part);
 }
 
+// The sampler as extra workgroups of another launch (the in-launch preparation pipeline of hsk_fused.hip: the batch two
+// steps ahead is sampled by workgroups riding in the forward's launch).  Same body, same draws as k_prep_sample.
+struct hsk_ride_sample {
+  int n_blocks;   // workgroups of this phase in the launch (0: none)
+  const int32_t* coo_user;
+  const int32_t* coo_item;
+  const int64_t* order;
+  long long start;
+  int B, n_neg;
+  const int64_t* csr_indptr;
+  const int32_t* csr_indices;
+  int n_items;
+  uint64_t seed, stream_id;
+  int *u32, *it32, *owner, *cnt;
+  int32_t* status;
+  hsk_alias at;
+  int* stamp;
+  int n_part;
+};
+
+__device__ __forceinline__ void hsk_ride_sample_body(const hsk_ride_sample& a, int bid) {
+  const int lane = hsk_lane();
+  const int wave = hsk_uniform_i(threadIdx.x >> 6);
+  const int b = bid * 4 + wave;
+  if (b >= a.B) return;
+  hsk_prep_sample_body(b, lane, wave, a.coo_user, a.coo_item, a.order, a.start, a.n_neg, a.csr_indptr, a.csr_indices,
+                       a.n_items, a.seed, a.stream_id, a.u32, a.it32, a.owner, a.cnt, a.status, 0, a.at, a.stamp, a.n_part);
+}
+
 // The batches of n_group consecutive steps of a replayed run in ONE launch (graph replay only: step / start / order come
 // from the descriptor): batch g = relative step rel0 + g, written to slot g of the per-batch buffers (gs_* = distance
 // between the slots, in elements).  Same draws as n_group launches of k_prep_sample.

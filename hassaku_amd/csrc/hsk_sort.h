@@ -88,13 +88,16 @@ __device__ __forceinline__ int hsk_sort_count(int n_entries, const int* __restri
   return n_dev ? min(n_entries, *n_dev) : n_entries;
 }
 
-__global__ __launch_bounds__(256) void k_sort_hist(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
-                                                   int* __restrict__ hist, const int* __restrict__ n_dev = nullptr) {
-  __shared__ int cnt[4][HSK_SORT_MAX_BUCKETS];
-  n_entries = hsk_sort_count(n_entries, n_dev);
+// Bodies + thin kernels: the same bodies also run as extra workgroups of the step's two big launches (the in-launch
+// preparation pipeline of hsk_fused.hip: `bid` = the workgroup's index inside its phase, LDS handed in by the caller).
+#define HSK_SORT_HIST_LDS (4 * HSK_SORT_MAX_BUCKETS)                             // ints of LDS of the histogram phase
+#define HSK_SORT_SCATTER_LDS (4 * HSK_SORT_MAX_BUCKETS + HSK_SORT_MAX_BUCKETS + 1)   // ... of the scatter phase
+__device__ __forceinline__ void hsk_sort_hist_body(const int* __restrict__ it32, int n_entries, const hsk_sort_plan& p,
+                                                   int* __restrict__ hist, int bid, int* __restrict__ cnt_lds) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + w;
-  for (int d = lane; d < p.n_buckets; d += 64) cnt[w][d] = 0;
+  int* cnt = cnt_lds + w * HSK_SORT_MAX_BUCKETS;
+  const int unit = bid * 4 + w;
+  for (int d = lane; d < p.n_buckets; d += 64) cnt[d] = 0;
   __syncthreads();
   if (unit < p.n_units) {
     const int lo = unit * p.epw, hi = min(n_entries, lo + p.epw);
@@ -107,18 +110,25 @@ __global__ __launch_bounds__(256) void k_sort_hist(const int* __restrict__ it32,
       }
 #pragma unroll
       for (int j = 0; j < HSK_SORT_GROUP; ++j)
-        if (key[j] >= 0) atomicAdd(&cnt[w][key[j]], 1);
+        if (key[j] >= 0) atomicAdd(&cnt[key[j]], 1);
     }
   }
   __syncthreads();
   if (unit < p.n_units)
-    for (int d = lane; d < p.n_buckets; d += 64) hist[d * p.n_units + unit] = cnt[w][d];
+    for (int d = lane; d < p.n_buckets; d += 64) hist[d * p.n_units + unit] = cnt[d];
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
+                                                   int* __restrict__ hist, const int* __restrict__ n_dev = nullptr) {
+  __shared__ int cnt[HSK_SORT_HIST_LDS];
+  hsk_sort_hist_body(it32, hsk_sort_count(n_entries, n_dev), p, hist, (int)blockIdx.x, cnt);
 }
 
 // one wave per bucket: exclusive scan of hist[d][0..NU) in place, btot[d] = row total
-__global__ __launch_bounds__(256) void k_sort_rowscan(int* __restrict__ hist, hsk_sort_plan p, int* __restrict__ btot) {
+__device__ __forceinline__ void hsk_sort_rowscan_body(int* __restrict__ hist, const hsk_sort_plan& p,
+                                                      int* __restrict__ btot, int bid) {
   const int lane = threadIdx.x & 63;
-  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int d = bid * 4 + (threadIdx.x >> 6);
   if (d >= p.n_buckets) return;
   int* row = hist + (long long)d * p.n_units;
   int v[HSK_SORT_MAX_UNITS / 64];
@@ -136,6 +146,10 @@ __global__ __launch_bounds__(256) void k_sort_rowscan(int* __restrict__ hist, hs
     carry += __shfl(incl, 63, 64);
   }
   if (lane == 0) btot[d] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_sort_rowscan(int* __restrict__ hist, hsk_sort_plan p, int* __restrict__ btot) {
+  hsk_sort_rowscan_body(hist, p, btot, (int)blockIdx.x);
 }
 
 // exclusive scan of btot[0..NB) into LDS bs[0..NB] by the calling workgroup's wave 0 (NB <= 512)
@@ -165,20 +179,19 @@ __device__ __forceinline__ void hsk_bucket_starts(const int* __restrict__ btot, 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_sort_scatter(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
+__device__ __forceinline__ void hsk_sort_scatter_body(const int* __restrict__ it32, int n_entries, const hsk_sort_plan& p,
                                                       const int* __restrict__ hist, const int* __restrict__ btot,
-                                                      int2* __restrict__ perm1, int* __restrict__ bstart,
-                                                      const int* __restrict__ n_dev = nullptr) {
-  n_entries = hsk_sort_count(n_entries, n_dev);
-  __shared__ int run[4][HSK_SORT_MAX_BUCKETS];
-  __shared__ int bs[HSK_SORT_MAX_BUCKETS + 1];
+                                                      int2* __restrict__ perm1, int* __restrict__ bstart, int bid,
+                                                      int* __restrict__ lds /* HSK_SORT_SCATTER_LDS ints */) {
+  int* bs = lds + 4 * HSK_SORT_MAX_BUCKETS;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + w;
+  int* run = lds + w * HSK_SORT_MAX_BUCKETS;
+  const int unit = bid * 4 + w;
   hsk_bucket_starts(btot, p.n_buckets, bs);
-  if (blockIdx.x == 0)
+  if (bid == 0)
     for (int d = threadIdx.x; d <= p.n_buckets; d += 256) bstart[d] = bs[d];
   if (unit >= p.n_units) return;  // no barrier below: every wave works on its own LDS row
-  for (int d = lane; d < p.n_buckets; d += 64) run[w][d] = bs[d] + hist[d * p.n_units + unit];
+  for (int d = lane; d < p.n_buckets; d += 64) run[d] = bs[d] + hist[d * p.n_units + unit];
   __builtin_amdgcn_wave_barrier();
   const int nbits = hsk_bits_for(p.n_buckets);
   const int lo = unit * p.epw, hi = min(n_entries, lo + p.epw);
@@ -196,25 +209,32 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const int* __restrict__ it
       const int key = valid ? (itemv[j] >> p.shift) : 0;
       const unsigned long long same = hsk_match_any(key, nbits, valid);
       const int rank = __popcll(same & ((1ull << lane) - 1ull));
-      const int base = run[w][key];
+      const int base = run[key];
       if (valid) perm1[base + rank] = make_int2(g0 + j * 64 + lane, itemv[j]);  // (entry, item)
       __builtin_amdgcn_wave_barrier();
-      if (valid && rank == 0) run[w][key] = base + __popcll(same);  // LDS ops of one wave execute in order
+      if (valid && rank == 0) run[key] = base + __popcll(same);  // LDS ops of one wave execute in order
       __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ perm1, int n_entries, int n_items,
-                                                     hsk_sort_plan p, const int* __restrict__ bstart,
+__global__ __launch_bounds__(256) void k_sort_scatter(const int* __restrict__ it32, int n_entries, hsk_sort_plan p,
+                                                      const int* __restrict__ hist, const int* __restrict__ btot,
+                                                      int2* __restrict__ perm1, int* __restrict__ bstart,
+                                                      const int* __restrict__ n_dev = nullptr) {
+  __shared__ int lds[HSK_SORT_SCATTER_LDS];
+  hsk_sort_scatter_body(it32, hsk_sort_count(n_entries, n_dev), p, hist, btot, perm1, bstart, (int)blockIdx.x, lds);
+}
+
+// lds: (5 * ipb + 2) ints, + ipb with `touched`
+__device__ __forceinline__ void hsk_sort_bucket_body(const int2* __restrict__ perm1, int n_entries, int n_items,
+                                                     const hsk_sort_plan& p, const int* __restrict__ bstart,
                                                      int* __restrict__ perm, int* __restrict__ offsets,
-                                                     int* __restrict__ touched = nullptr,
-                                                     int* __restrict__ n_touched = nullptr,
-                                                     const int* __restrict__ n_dev = nullptr) {
-  n_entries = hsk_sort_count(n_entries, n_dev);
+                                                     int* __restrict__ touched, int* __restrict__ n_touched, int bid,
+                                                     int* __restrict__ lds) {
   // touched / n_touched (optional): compact list of the items that have entries, any order (lazy item AdamW:
-  // hsk_fused.hip); needs ipb + 2 more ints of dynamic LDS
-  extern __shared__ int lds[];  // cnt[4][ipb] then tot[ipb] [then list[ipb], count, base]
+  // hsk_fused.hip); needs ipb + 2 more ints of LDS
+  // lds: cnt[4][ipb] then tot[ipb] [then list[ipb], count, base]
   const int ipb = p.ipb;
   int* cnt = lds;
   int* tot = lds + 4 * ipb;
@@ -222,7 +242,7 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
   int* tmeta = lds + 6 * ipb;   // [0] items with entries in this bucket, [1] their base in `touched`
   if (touched && threadIdx.x == 0) tmeta[0] = 0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b = blockIdx.x;
+  const int b = bid;
   const int beg = bstart[b], end = bstart[b + 1];
   const int n = end - beg;
   const int per = ((n + 3) / 4 + 63) / 64 * 64;  // entries per wave, multiple of 64 so chunks stay aligned
@@ -302,6 +322,33 @@ __global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ pe
   }
 }
 
+__global__ __launch_bounds__(256) void k_sort_bucket(const int2* __restrict__ perm1, int n_entries, int n_items,
+                                                     hsk_sort_plan p, const int* __restrict__ bstart,
+                                                     int* __restrict__ perm, int* __restrict__ offsets,
+                                                     int* __restrict__ touched = nullptr,
+                                                     int* __restrict__ n_touched = nullptr,
+                                                     const int* __restrict__ n_dev = nullptr) {
+  extern __shared__ int lds[];
+  hsk_sort_bucket_body(perm1, hsk_sort_count(n_entries, n_dev), n_items, p, bstart, perm, offsets, touched, n_touched,
+                       (int)blockIdx.x, lds);
+}
+
+
+// One phase of the two-level sort as extra workgroups of another launch (the in-launch preparation pipeline of
+// hsk_fused.hip): which phase is said by where the struct sits (hsk_ride_fwd / hsk_ride_item).
+#define HSK_PIPE_MAX_IPB 128   // items per bucket the riding bucket phase holds counters for (5 * ipb + 2 ints of LDS)
+struct hsk_ride_sort {
+  int n_blocks;   // workgroups of this phase in the launch (0: none)
+  const int* it32;
+  int n_entries, n_items;
+  hsk_sort_plan plan;
+  int* hist;
+  int* btot;
+  int2* perm1;
+  int* bstart;
+  int* perm;
+  int* offsets;
+};
 
 // ---------------------------------------------------------------------------------------------
 // Small batches (<= 1024 * IPT entries): the whole sort in ONE workgroup.  At B = 128, N = 50 the four level-1/2

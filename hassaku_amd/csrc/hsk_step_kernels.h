@@ -39,6 +39,17 @@ __device__ __forceinline__ hsk_adamw_consts hsk_consts_lane(const hsk_adamw_cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sharded step (hsk_shard.inc): a batch that exceeded a capacity must never update a table.  k_shard_place raises *ovf
+// (one word per buffer set) for such a batch; the kernel that OPENS its step (k_user_catch_up, launched by hsk_shard_pack)
+// then raises the sticky *poison, and every table-writing kernel of this and of all later steps returns at once: the
+// tables stay what they were before the first overflowing step until the host reads HSK_STATUS_SHARD_OVERFLOW and raises.
+// One scalar load (two) per workgroup.  NULL pointers (the single-GPU step): no guard.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool hsk_guard_skip(const int* __restrict__ ovf, const int* __restrict__ poison) {
+  return (ovf && __builtin_nontemporal_load(ovf) != 0) || (poison && __builtin_nontemporal_load(poison) != 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Lazy user rows inside the forward.  A user row outside the previous batches carries pending zero-gradient AdamW
 // steps (see "Lazy, exact user-table AdamW" below).  Instead of a separate catch-up launch that rewrites the row
 // before the forward reads it, the forward replays the missed steps IN REGISTERS on its own copy (p, m, v of the row:
@@ -288,7 +299,10 @@ __global__ __launch_bounds__(256) void k_item_update(const float* __restrict__ U
                                                      const float* __restrict__ g_s, const int* __restrict__ perm,
                                                      const int* __restrict__ offsets,
                                                      int n_items, int K, int D, hsk_adamw_consts c,
-                                                     float* __restrict__ gI_out, float* __restrict__ gIb_out) {
+                                                     float* __restrict__ gI_out, float* __restrict__ gIb_out,
+                                                     const int* __restrict__ g_ovf = nullptr,
+                                                     const int* __restrict__ g_poison = nullptr) {
+  if (APPLY && hsk_guard_skip(g_ovf, g_poison)) return;
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
   const int i = blockIdx.x * 4 + wave;
@@ -546,8 +560,15 @@ __global__ __launch_bounds__(256) void k_user_catch_up(float* __restrict__ Uw, f
                                                        int* __restrict__ last_step, int B, int D, int step,
                                                        hsk_adamw_consts c, const float2* __restrict__ tab,
                                                        int tab_len, int* __restrict__ dupcnt = nullptr,
-                                                       int* __restrict__ duplist = nullptr) {
+                                                       int* __restrict__ duplist = nullptr,
+                                                       const int* __restrict__ g_ovf = nullptr,
+                                                       int* __restrict__ g_poison = nullptr, int g_open = 0) {
   const int b = blockIdx.x;
+  if (g_poison) {   // sharded step (hsk_guard_skip); g_open: this launch opens the step of the batch *g_ovf speaks of
+    const bool over = g_ovf && __builtin_nontemporal_load(g_ovf) != 0;
+    if (over && g_open && b == 0 && threadIdx.x == 0) *g_poison = 1;
+    if (over || __builtin_nontemporal_load(g_poison) != 0) return;
+  }
   const int row = u32[b];
   if (row < 0) return;  // empty exchange slot (row-sharded mode)
   // row loads issued together with the owner / last_step lookups; thrown away by non-owners and current rows
@@ -619,7 +640,10 @@ __global__ __launch_bounds__(256) void k_item_catch_up(float* __restrict__ Iw, f
                                                        int D, int step, hsk_adamw_consts c,
                                                        const float2* __restrict__ tab, int tab_len,
                                                        const hsk_step_desc* __restrict__ desc = nullptr, int rel = 0,
-                                                       int* __restrict__ pend = nullptr) {
+                                                       int* __restrict__ pend = nullptr,
+                                                       const int* __restrict__ g_ovf = nullptr,
+                                                       const int* __restrict__ g_poison = nullptr) {
+  if (hsk_guard_skip(g_ovf, g_poison)) return;
   if (desc) step = desc->step0 + rel + 1;   // graph replay (c's per-step fields are rebuilt per replayed step below)
   if ((int)blockIdx.x >= *n_touched) return;
   const int row = touched[blockIdx.x];
@@ -862,7 +886,9 @@ __device__ __forceinline__ void hsk_user_update_lazy_body(const hsk_user_lazy_ar
 }
 
 template <int V, int NCH, bool FULL, bool GEN, bool PART = false>
-__global__ __launch_bounds__(256) void k_user_update_lazy(hsk_user_lazy_args a) {
+__global__ __launch_bounds__(256) void k_user_update_lazy(hsk_user_lazy_args a, const int* __restrict__ g_ovf = nullptr,
+                                                          const int* __restrict__ g_poison = nullptr) {
+  if (hsk_guard_skip(g_ovf, g_poison)) return;
   hsk_user_update_lazy_body<V, NCH, FULL, GEN, PART>(a, (int)blockIdx.x);
 }
 
@@ -995,7 +1021,9 @@ __global__ __launch_bounds__(256) void k_user_flush(float* __restrict__ Uw, floa
                                                     float* __restrict__ vU, float* __restrict__ Ub,
                                                     float* __restrict__ mUb, float* __restrict__ vUb,
                                                     int* __restrict__ last_step, int n_users, int D, int step,
-                                                    hsk_adamw_consts c, const float2* __restrict__ tab, int tab_len) {
+                                                    hsk_adamw_consts c, const float2* __restrict__ tab, int tab_len,
+                                                    const int* __restrict__ g_poison = nullptr) {
+  if (hsk_guard_skip(nullptr, g_poison)) return;
   const int row = blockIdx.x;
   const int done = last_step[row];
   if (done >= step) return;

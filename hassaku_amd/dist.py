@@ -16,6 +16,10 @@ Per step and rank (C = user slots per owner ~ B + 6 sigma, G = W*B):
     all_reduce      s0           [G]                  positive scores, computed by the positive item's owner
     all_reduce      gsum         [G]                  per positive: sum of its negatives' weights over the ranks
     reduce_scatter  user grads   [W*C, D] -> [C, D]   4*D*C bytes to every peer     (everyone -> owner)
+The two scalar reductions are what the BPR loss costs (a positive is coupled to ALL its negatives).  The reference's
+other two losses ride the same exchange of rows (nn.DataParallel is loss-agnostic, train/rec_losses.py:27-139):
+bce needs NO scalar collective (every logit is weighed on its own); sampled softmax needs one all_gather of the ranks'
+(running max, normaliser, s0) triples, [3G] -> [W, 3G], in their place.
 The all_gather runs under the preparation (sampling, routing, item sort) of the NEXT batch, which is issued a step
 ahead on a side stream; the reduce_scatter runs under the local item-gradient pass + item AdamW.  xGMI is a
 point-to-point mesh: all_gather / reduce_scatter use all 7 links of a GPU at once (4*D*C bytes per link).
@@ -217,13 +221,22 @@ class ShardedBprMf:
                  beta2=ADAM_BETA2, eps=None, capacity: Optional[int] = None, entry_cap: Optional[int] = None,
                  loss='bpr', log_adjust=0.0, alias=None, optimizer='adamw', lazy_items='auto', prefetch=True,
                  inputs_are_shards=False, n_users: Optional[int] = None, n_items: Optional[int] = None,
-                 flush_every: int = 0, item_shard=None):
+                 flush_every: int = 0, item_shard=None, native='auto'):
+        """native: who issues the step.  True: ONE C call per step (hsk_shard_step), the collectives on the library's own
+        RCCL communicator; False: phase by phase from here, torch.distributed in between; 'host-staged': hsk_shard_step over
+        the library's host-staged collectives -- for ranks that are processes sharing one GPU (tests: RCCL refuses two ranks
+        on one device); 'auto': HSK_SHARD_NATIVE=1 / 0 if set, else True on a one-rank nccl group and False otherwise --
+        the natively issued step at world > 1 is taken only when asked for (bench.py asks after it has checked it bit for
+        bit against the phased path on the job's own ranks)."""
         _lib.require_gpu()
         self.lib = _lib.load()
         self.comm = comm
         W, r = comm.world, comm.rank
-        if loss != 'bpr':
-            raise ValueError(f"the sharded step implements the bpr loss (got {loss!r}); other losses train on one GPU")
+        if loss not in hip_ops.LOSS_KINDS:
+            raise ValueError(f'unknown loss {loss!r}')
+        if loss == 'bce' and (user_bias is not None or global_bias is not None):
+            raise ValueError('bce sends gradient to the user / global bias: the sharded step does not carry them')
+        self.loss = loss
         dev = user_emb.device
         D = user_emb.shape[1]
         if inputs_are_shards:
@@ -318,6 +331,9 @@ class ShardedBprMf:
         self.grads_mine = torch.zeros((C, D), dtype=torch.float32, device=dev)
         self.s0 = torch.zeros(G, dtype=torch.float32, device=dev)
         self.gsum = torch.zeros(G, dtype=torch.float32, device=dev)
+        # sampled softmax: the ranks' (running max, normaliser, s0) triples travel in one all_gather
+        self.ssm_send = torch.zeros(3 * G, dtype=torch.float32, device=dev) if loss == 'sampled_softmax' else None
+        self.ssm_all = torch.zeros(W * 3 * G, dtype=torch.float32, device=dev) if loss == 'sampled_softmax' else None
 
         sh = HskBprmfShard()
         st = sh.base
@@ -345,7 +361,7 @@ class ShardedBprMf:
             # 0.73, 7.6 against 7.9 ms per step) -- i.e. entries / rows < 1.5.
             lazy_items = D % 2 == 0 and I_loc >= 0.66 * cap and I_loc * D > hip_ops.LAZY_USERS_MIN_ELEMENTS
         st.lazy_items = 1 if lazy_items else 0
-        st.timing_mask, st.timing, st.aux, st.timing_every, st.timing_now = 0, None, None, 1, 0
+        st.timing_mask, st.timing, st.aux, st.timing_every = 0, None, None, 1
         st.loss_kind, st.ssm_log_adjust = hip_ops.LOSS_KINDS[loss], float(log_adjust)
         self.alias = alias
         st.alias_prob, st.alias_idx = (None, None) if alias is None else (_p(alias[0]), _p(alias[1]))
@@ -357,6 +373,7 @@ class ShardedBprMf:
         sh.rows_send, sh.rows_all = _p(self.rows_send), _p(self.rows_all)
         sh.dU_all, sh.grads_mine = _p(self.dU_all), _p(self.grads_mine)
         sh.s0, sh.gsum = _p(self.s0), _p(self.gsum)
+        sh.ssm_send, sh.ssm_all = _p(self.ssm_send), _p(self.ssm_all)
         self.sh = sh
         _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(sh.base), _stream()), 'hsk_bprmf_init_workspace')
         _lib.check(self.lib.hsk_shard_init(ctypes.byref(sh), _stream()), 'hsk_shard_init')
@@ -366,35 +383,71 @@ class ShardedBprMf:
         self._cur_set = 0
         self._pf = None          # (order ptr, start, batch, step index it is for, set, order tensor kept alive)
         self._prefetch = bool(prefetch)
-        # Backend nccl: the whole step is issued from ONE C call with the collectives called on RCCL directly
-        # (csrc/hsk_rccl.inc: hsk_shard_step) -- the phase-by-phase sequence below costs ten Python / torch dispatches
-        # per step and leaves the GPU idle in between.  The library opens its own communicator over the same ranks; the
-        # 128-byte id travels through this process group.  HSK_SHARD_NATIVE=0 keeps the phased path (same results).
+        # The whole step from ONE C call (csrc/hsk_rccl.inc: hsk_shard_step) -- the phase-by-phase sequence below costs ten
+        # Python / torch dispatches per step and leaves the GPU idle in between.  The library opens its own communicator
+        # over the same ranks; the 128-byte id travels through this process group.
         self._rt = None
         self._order_keep = None
         import os
-        if isinstance(comm, Comm) and comm.native and os.environ.get('HSK_SHARD_NATIVE', '1') != '0' \
-                and self.lib.hsk_rccl_available():
-            idb = torch.zeros(128, dtype=torch.uint8)
-            if r == 0:
-                buf = (ctypes.c_ubyte * 128)()
-                _lib.check(self.lib.hsk_rccl_unique_id(buf), 'hsk_rccl_unique_id')
-                idb = torch.tensor(list(buf), dtype=torch.uint8)
-            idd = idb.to(dev)
-            comm.broadcast(idd, src=0)
-            raw = bytes(idd.cpu().tolist())
-            rt = self.lib.hsk_shard_rt_create(W, r, ctypes.c_char_p(raw))
-            # every rank takes the native path or none does (a rank on its own in the phased path would wait for ever)
-            ok = torch.tensor([1.0 if rt else 0.0], device=dev)
-            comm.all_reduce(ok)
-            if int(ok.item()) == W:
-                self._rt = ctypes.c_void_p(rt)
-            else:
-                import warnings
-                warnings.warn('hsk_shard_rt_create failed on a rank (' + self.lib.hsk_last_error().decode('utf-8', 'replace')
-                              + '): the sharded step falls back to the phase-by-phase path')
-                if rt:
-                    self.lib.hsk_shard_rt_destroy(ctypes.c_void_p(rt))
+        if native == 'auto':
+            env = os.environ.get('HSK_SHARD_NATIVE')
+            native = (env == '1') if env in ('0', '1') else (W == 1 and isinstance(comm, Comm) and comm.native)
+        if native == 'host-staged':
+            if not isinstance(comm, Comm):
+                raise ValueError("native='host-staged' needs a process group to hand the segment's name around")
+            self._open_runtime(lambda buf: self.lib.hsk_hostcoll_unique_id(W * C * D, buf), 'hsk_hostcoll_unique_id')
+        elif native:
+            if not (isinstance(comm, Comm) and comm.native and self.lib.hsk_rccl_available()):
+                raise RuntimeError('native=True needs backend nccl and a loadable librccl')
+            self._open_runtime(self.lib.hsk_rccl_unique_id, 'hsk_rccl_unique_id')
+
+    def _open_runtime(self, make_id, what):
+        comm, W, r, dev = self.comm, self.comm.world, self.comm.rank, self.device
+        idb = torch.zeros(128, dtype=torch.uint8)
+        if r == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            _lib.check(make_id(buf), what)
+            idb = torch.tensor(list(buf), dtype=torch.uint8)
+        idd = idb.to(dev)
+        comm.broadcast(idd, src=0)
+        raw = bytes(idd.cpu().tolist())
+        rt = self.lib.hsk_shard_rt_create(W, r, ctypes.c_char_p(raw))
+        # every rank takes the native path or none does (a rank on its own in the phased path would wait for ever)
+        ok = torch.tensor([1.0 if rt else 0.0], device=dev)
+        comm.all_reduce(ok)
+        if int(ok.item()) == W:
+            self._rt = ctypes.c_void_p(rt)
+        else:
+            import warnings
+            warnings.warn('hsk_shard_rt_create failed on a rank (' + self.lib.hsk_last_error().decode('utf-8', 'replace')
+                          + '): the sharded step falls back to the phase-by-phase path')
+            if rt:
+                self.lib.hsk_shard_rt_destroy(ctypes.c_void_p(rt))
+
+    @property
+    def issued_natively(self) -> bool:
+        return self._rt is not None
+
+    def backend(self) -> str:
+        """who moves the bytes: 'rccl' / 'host-staged' (hsk_shard_step) or 'torch.distributed:<backend>' (phased)"""
+        if self._rt is not None:
+            return self.lib.hsk_shard_rt_backend(self._rt).decode()
+        return 'torch.distributed:' + ('nccl' if getattr(self.comm, 'native', False) else 'staged')
+
+    def set_hyper(self, lr=None, wd=None, beta1=None, beta2=None, eps=None):
+        """Change lr / wd / betas / eps between steps (an LR schedule) -- on EVERY rank, with the same values.  The
+        per-step Adam scalars of the lazy replay are a device table computed from the hyper-parameters, so: flush under
+        the old values, install the new ones, prepare the workspace again (train/trainer.py:52-53 of the reference builds
+        its optimiser once; torch schedulers mutate param_groups[...]['lr'] the same way)."""
+        self.flush()
+        torch.cuda.synchronize()
+        st = self.sh.base
+        for name, val in (('lr', lr), ('wd', wd), ('beta1', beta1), ('beta2', beta2), ('eps', eps)):
+            if val is not None:
+                setattr(st, name, float(val))
+        _lib.check(self.lib.hsk_bprmf_init_workspace(ctypes.byref(st), _stream()), 'hsk_bprmf_init_workspace')
+        _lib.check(self.lib.hsk_shard_init(ctypes.byref(self.sh), _stream()), 'hsk_shard_init')
+        self._pf = None
 
     @property
     def step_count(self) -> int:
@@ -457,9 +510,13 @@ class ShardedBprMf:
             self._pf = (_p(order), int(next_start), nnb, self.step_count + 1, set_ ^ 1, order)
         rows.wait()
         _lib.check(lib.hsk_shard_pos_scores(ref, s), 'hsk_shard_pos_scores')
-        comm.all_reduce(self.s0[:G])
+        if self.loss == 'bpr':                       # (bce: no scalar exchange at all)
+            comm.all_reduce(self.s0[:G])
         _lib.check(lib.hsk_shard_forward(ref, s), 'hsk_shard_forward')
-        comm.all_reduce(self.gsum[:G])
+        if self.loss == 'bpr':
+            comm.all_reduce(self.gsum[:G])
+        elif self.loss == 'sampled_softmax':         # the ranks' (max, normaliser, s0) triples: [3G] -> [W, 3G]
+            comm.all_gather_into(self.ssm_all[:comm.world * 3 * G], self.ssm_send[:3 * G])
         _lib.check(lib.hsk_shard_pos_fix(ref, s), 'hsk_shard_pos_fix')
         grads = comm.reduce_scatter(self.grads_mine, self.dU_all, async_op=True)
         _lib.check(lib.hsk_shard_apply_items(ref, s), 'hsk_shard_apply_items')     # under the reduce_scatter

@@ -410,7 +410,6 @@ class BprMfFusedState:
         st.alias_prob, st.alias_idx = (None, None) if alias is None else (_p(alias[0]), _p(alias[1]))
         st.timing = None
         st.timing_every = 1
-        st.timing_now = 0
         self._timing = None
         # optional side stream: the batch named by hint_next() is sampled and item-sorted there while the current
         # step's item / user passes run (cross-step prefetch; results identical to the un-hinted sequence)
@@ -468,6 +467,10 @@ class BprMfFusedState:
         """Runs of steps_sampled() issued as replayed HIP graphs so far."""
         return int(self.lib.hsk_bprmf_graph_replays(ctypes.byref(self.st)))
 
+    def pipelined_steps(self) -> int:
+        """Steps of steps_sampled() issued with the next batches' preparation riding in the steps' own launches."""
+        return int(self.lib.hsk_bprmf_pipelined_steps(ctypes.byref(self.st)))
+
     def hint_next(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int):
         """Name the batch of the NEXT step_sampled call so that the step issued now prepares it on the side stream.
         No-op without overlap=True.  batch <= 0 clears a pending hint."""
@@ -481,14 +484,15 @@ class BprMfFusedState:
         _lib.check(self.lib.hsk_bprmf_hint_next(ctypes.byref(self.st), _p(order), start, batch, n_neg),
                    'hsk_bprmf_hint_next')
 
-    def hint_after_run(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int):
-        """Name the batch that follows the NEXT steps_sampled() run: its last step prepares it on the side stream, so
-        an epoch issued in several runs keeps its prefetch pipeline full.  No-op without overlap=True."""
+    def hint_after_run(self, order: Optional[torch.Tensor], start: int, batch: int, n_neg: int, n_batches: int = 1):
+        """Name the `n_batches` consecutive batches that follow the NEXT steps_sampled() run: the run's last steps prepare
+        them (side stream, or -- large batches -- riding in the steps' own launches, which works two batches ahead), so
+        an epoch issued in several runs keeps its preparation pipeline full.  No-op without overlap=True."""
         if self._aux is None:
             return
         self._hint_order = order
-        _lib.check(self.lib.hsk_bprmf_hint_after_run(ctypes.byref(self.st), _p(order), start, batch, n_neg),
-                   'hsk_bprmf_hint_after_run')
+        _lib.check(self.lib.hsk_bprmf_hint_after_run_n(ctypes.byref(self.st), _p(order), start, batch, n_neg,
+                                                       int(n_batches)), 'hsk_bprmf_hint_after_run_n')
 
     def last_batch(self, batch: int, n_cols: int):
         u = torch.empty(batch, dtype=torch.int64, device=self.device)

@@ -62,10 +62,10 @@ class Trainer:
         if fusable and isinstance(rec_loss, RecBinaryCrossEntropy) and (model.use_user_bias or model.use_global_bias):
             fusable = False   # bce does send gradient to the user / global bias: autograd path
         if multi:
-            if not (fusable and isinstance(train_loader, TrainDataLoader)
-                    and isinstance(rec_loss, RecBayesianPersonalizedRankingLoss)):
-                raise RuntimeError('multi-GPU training supports mf + bpr + {adamw, adam, adagrad} with the device '
-                                   'TrainDataLoader (other losses train on one GPU)')
+            # (bce with a user / global bias sends gradient to them: `fusable` is False then, as on one GPU)
+            if not (fusable and isinstance(train_loader, TrainDataLoader)):
+                raise RuntimeError('multi-GPU training supports mf + {bpr, bce, sampled_softmax} + {adamw, adam, adagrad} '
+                                   'with the device TrainDataLoader')
             self.sharded = self._build_sharded(conf)
             self.optimizer = None
         elif want_fused and fusable:
@@ -245,8 +245,11 @@ class Trainer:
                 if k + run < len(batches) and run == 1:
                     fused.hint_next(*batches[k + 1], n_neg)
                 if run > 1:
-                    if k + run < len(batches):            # the run's last step prepares the next run's first batch
-                        fused.hint_after_run(*batches[k + run], n_neg)
+                    if k + run < len(batches):            # the run's last steps prepare the next run's first batches
+                        nxt = batches[k + run]
+                        two = (k + run + 1 < len(batches) and batches[k + run + 1][2] == nxt[2]
+                               and batches[k + run + 1][1] == nxt[1] + nxt[2] and batches[k + run + 1][0] is nxt[0])
+                        fused.hint_after_run(*nxt, n_neg, n_batches=2 if two else 1)
                     fused.steps_sampled(order, start, run, nb, n_neg)
                 else:
                     fused.step_sampled(order, start, nb, n_neg)

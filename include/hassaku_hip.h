@@ -168,6 +168,7 @@ int hsk_sample_negatives_alias(const int64_t* csr_indptr, const int32_t* csr_ind
  * ------------------------------------------------------------------------------------------ */
 
 typedef struct hsk_bprmf_state {
+  /* ---- caller-owned: parameters, optimiser state, shapes ------------------------------------------------------- */
   /* parameters: user_emb [U,D], item_emb [I,D], item_bias [I], user_bias [U], global_bias [1];
      bias pointers NULL when disabled (algorithms/sgd_alg.py:127-138) */
   float* user_emb;
@@ -182,7 +183,10 @@ typedef struct hsk_bprmf_state {
   float* m_user_bias;  float* v_user_bias;
   float* m_global_bias; float* v_global_bias;
   int64_t n_users, n_items, dim;
-  /* hyper-parameters (conf keys lr, wd; betas/eps = torch defaults unless overridden) */
+  /* hyper-parameters (conf keys lr, wd; betas/eps = torch defaults unless overridden).  FROZEN once
+     hsk_bprmf_init_workspace has run (the per-step Adam scalars of the lazy replay and of replayed graphs are a device
+     table computed from them): a call that finds lr / betas / eps / wd / opt_kind changed fails with HSK_ERR_INVALID
+     instead of mixing two schedules -- flush, set the new values, call hsk_bprmf_init_workspace again */
   double lr, beta1, beta2, eps, wd;
   /* number of optimizer steps applied so far; hsk_bprmf_train_step* increments it (host side) */
   int64_t step;
@@ -197,6 +201,7 @@ typedef struct hsk_bprmf_state {
   void* workspace;
   int64_t workspace_bytes;
   int64_t max_batch, max_cols;
+  /* ---- caller-owned: options ----------------------------------------------------------------------------------- */
   /* lazy user-table AdamW: 0 = dense sweep every step (reference order of operations),
      1 = exact lazy catch-up of untouched rows (needs hsk_bprmf_flush before reading user tables) */
   int32_t lazy_users;
@@ -207,9 +212,8 @@ typedef struct hsk_bprmf_state {
   /* opaque handle from hsk_aux_create, or NULL: side stream on which the batch named by hsk_bprmf_hint_next is
      sampled and item-sorted while the current step's item / user passes run (fork / join by events) */
   void* aux;
-  /* event-time only every timing_every-th step (<= 1: every step); timing_now is library scratch */
+  /* event-time only every timing_every-th step (<= 1: every step) */
   int32_t timing_every;
-  int32_t timing_now;
   /* recommendation loss of the fused step (train/rec_losses.py): HSK_LOSS_BPR (default, 0), HSK_LOSS_BCE,
      HSK_LOSS_SSM (sampled softmax; ssm_log_adjust = log(n_items / neg_train) for uniform sampling, else 0) */
   int32_t loss_kind;
@@ -217,15 +221,15 @@ typedef struct hsk_bprmf_state {
      HSK_OPT_ADAGRAD.  m_* = exp_avg (unused by adagrad, must still be valid memory), v_* = exp_avg_sq /
      adagrad's state_sum.  torch defaults: eps 1e-8 (adam, adamw), 1e-10 (adagrad); betas only for adam / adamw */
   int32_t opt_kind;
+  /* 1: lazy, exact AdamW on the ITEM tables too (same scheme as lazy_users: a row outside the batch keeps its
+     zero-gradient steps until it is next touched or flushed; bit-identical to the dense update).  For catalogues far
+     larger than a batch touches; needs an even dim.  0 (default): every item row is updated every step */
+  int32_t lazy_items;
   double ssm_log_adjust;
   /* negative sampling law of the device sampler: NULL = uniform; otherwise a Walker alias table over the items
      (alias_prob float[I], alias_idx int32[I]) = train_neg_strategy 'popular' (data/dataloader.py:59-64) */
   const float* alias_prob;
   const int32_t* alias_idx;
-  /* 1: lazy, exact AdamW on the ITEM tables too (same scheme as lazy_users: a row outside the batch keeps its
-     zero-gradient steps until it is next touched or flushed; bit-identical to the dense update).  For catalogues far
-     larger than a batch touches; needs an even dim.  0 (default): every item row is updated every step */
-  int32_t lazy_items;
   /* hsk_bprmf_train_steps replays its steady-state loop as captured HIP graphs of this many steps (0: default 64,
      < 0: never, eager launches only); per-step scalars are read from a device descriptor, results are bit-identical */
   int32_t graph_chunk;
@@ -233,7 +237,6 @@ typedef struct hsk_bprmf_state {
      the forward kernel, in registers (fastest step); 1: by a stand-alone launch in front of it (the forward is then a
      pure gather -- what bench.py times as `roofline.pure_gather`); results are bit-identical */
   int32_t catchup_apart;
-  int32_t reserved3;
   /* outputs: loss_out[0] = loss of the last step (fp64), loss_out[1] += that loss (epoch sum) */
   double* loss_out;
   int32_t* status;
@@ -245,13 +248,14 @@ typedef struct hsk_bprmf_state {
      its exchange buffers: the [max_batch, dim] row buffers of the single-GPU step are not allocated.  The size is then
      hsk_shard_base_workspace_bytes(); the single-GPU entry points refuse such a state */
   int32_t ws_sharded;
-  /* library scratch, written by hsk_bprmf_init_workspace: the hyper-parameters the workspace was prepared for (the
-     per-step Adam scalars of the lazy replay and of replayed graphs live in a device table computed from them).
-     lr / beta1 / beta2 / eps / wd / opt_kind are FROZEN from then on: a call that finds them changed fails with
-     HSK_ERR_INVALID instead of mixing two schedules -- flush, set the new values, call hsk_bprmf_init_workspace again */
+  /* ---- LIBRARY SCRATCH: zero-initialise, never write ----------------------------------------------------------- */
+  /* written by hsk_bprmf_init_workspace: the hyper-parameters (and optimiser) the workspace was prepared for */
   double frozen_hyper[5];
   int32_t frozen_opt;
   int32_t frozen_valid;
+  /* whether the step being issued is an event-timed one (from timing_every) */
+  int32_t timing_now;
+  int32_t reserved3;
 } hsk_bprmf_state;
 
 int64_t hsk_bprmf_workspace_bytes(int64_t n_users, int64_t n_items, int64_t dim,
@@ -332,9 +336,19 @@ int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, int64_t sta
  * full across the calls.  Same rules as hsk_bprmf_hint_next; consumed by (and cleared after) the next run; ignored by
  * runs replayed as graphs, which prepare their first batch themselves.  batch <= 0 clears it. */
 int hsk_bprmf_hint_after_run(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch, int64_t n_neg);
+/* The same, naming the n_batches consecutive batches order[start + j*batch .. +batch), j < n_batches, that follow the
+ * next run.  Large batches (the item-partitioned forward) prepare a batch over the TWO steps in front of its own -- its
+ * sampling and the phases of its item sort ride as extra workgroups in those steps' launches (csrc/hsk_fused.hip:
+ * hsk_pipe_step) -- so an epoch loop issued in several runs names two batches to keep that pipeline full across the
+ * calls; hsk_bprmf_hint_after_run names one. */
+int hsk_bprmf_hint_after_run_n(hsk_bprmf_state* st, const int64_t* order, int64_t start, int64_t batch, int64_t n_neg,
+                               int64_t n_batches);
 
 /* number of runs hsk_bprmf_train_steps has issued as replayed graphs so far (0 when every step was launched eagerly) */
 int64_t hsk_bprmf_graph_replays(const hsk_bprmf_state* st);
+/* number of steps hsk_bprmf_train_steps has issued with the next batches' preparation riding in the steps' own launches
+ * (large batches; 0 when every step used the side-stream prefetch) */
+int64_t hsk_bprmf_pipelined_steps(const hsk_bprmf_state* st);
 
 /* Bring lazily-updated user / item rows up to st->step (no-op with dense updates); also drops a pending hint and a
  * prefetched batch that was never trained on (a flush ends a run of steps). */
@@ -398,9 +412,25 @@ int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries, int32_t* p
  *                          loss_out[1] accumulates it.  Closes the step.
  *
  * Result = the single-GPU step on the global batch (same samples; the fp32 sums over a positive's negatives are split
- * by owner, so the order of summation differs).  C = user slots per owner, entry_cap = kept entries per rank; if either
- * is too small HSK_STATUS_SHARD_OVERFLOW is raised in *status (the step is then invalid).  BPR loss only.
- * world == 1 is accepted (the collectives degenerate to copies): the same code path on one GPU.
+ * by owner, so the order of summation differs).  world == 1 is accepted (the collectives degenerate to copies): the
+ * same code path on one GPU.
+ *
+ * Losses (base.loss_kind; nn.DataParallel in the reference is loss-agnostic, train/trainer.py:38-41 with
+ * train/rec_losses.py:27-139).  The protocol above is the BPR one.  Differences:
+ *   HSK_LOSS_BCE  every logit is weighed on its own: NO scalar collective at all -- the positive's owner uses its own s0
+ *                 (skip both all_reduces; hsk_shard_pos_fix adds the positive's term from sh->s0 as it stands)
+ *   HSK_LOSS_SSM  sampled softmax: hsk_shard_pos_scores leaves the owner's s0 in the third plane of ssm_send,
+ *                 hsk_shard_forward the rank's running max and normaliser over ITS negatives in the first two;
+ *                   all_gather(ssm_send [3*G] -> ssm_all [world, 3*G])           12*G bytes to every peer
+ *                 replaces both all_reduces; hsk_shard_pos_fix then combines the pairs (identically on every rank),
+ *                 scales the rank's partial gradient rows and weights, and adds the positive's term at its owner.
+ *
+ * Capacities.  C = user slots per owner, entry_cap = kept entries per rank; if either is too small for a batch
+ * HSK_STATUS_SHARD_OVERFLOW is raised in *status when that batch is PREPARED, and when its step opens (hsk_shard_pack)
+ * every table-writing kernel of that step AND OF EVERY LATER STEP returns without writing (a device-side guard, one scalar
+ * load per workgroup): the tables -- hsk_shard_flush included -- stay exactly what they were before the first overflowing
+ * step, however late the host reads the status word.  Such a state cannot be trained further: rebuild it with larger
+ * capacities.
  * ------------------------------------------------------------------------------------------ */
 enum { HSK_STATUS_SHARD_OVERFLOW = 4 };
 
@@ -418,11 +448,14 @@ typedef struct hsk_bprmf_shard {
   float* rows_all;            /* [world*C, D]    all_gather output */
   float* dU_all;              /* [world*C, D]    reduce_scatter input (zero-initialised by the caller) */
   float* grads_mine;          /* [C, D]          reduce_scatter output */
-  float* s0;                  /* [world*batch]   all_reduce in place */
-  float* gsum;                /* [world*batch]   all_reduce in place */
-  int64_t cur_batch, cur_cols; /* library scratch: shape of the step in flight (0: none) */
-  int32_t cur_set;             /* library scratch: buffer set of the step in flight */
-  int32_t phase;               /* library scratch: next expected phase */
+  float* s0;                  /* [world*batch]   bpr: all_reduce in place; bce: the owners' scores, not exchanged */
+  float* gsum;                /* [world*batch]   bpr: all_reduce in place */
+  float* ssm_send;            /* [3, world*batch]        sampled softmax only (else may be NULL): all_gather input */
+  float* ssm_all;             /* [world, 3, world*batch] sampled softmax only: all_gather output */
+  /* ---- LIBRARY SCRATCH: zero-initialise, never write ----------------------------------------------------------- */
+  int64_t cur_batch, cur_cols; /* shape of the step in flight (0: none) */
+  int32_t cur_set;             /* buffer set of the step in flight */
+  int32_t phase;               /* next expected phase */
 } hsk_bprmf_shard;
 
 int64_t hsk_shard_workspace_bytes(int64_t max_batch, int64_t max_cols, int64_t capacity, int64_t entry_cap);
@@ -448,23 +481,48 @@ int hsk_shard_last_batch(const hsk_bprmf_shard* sh, int32_t set, int64_t batch, 
                          int32_t* u_out, hsk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * The sharded step issued from ONE C call, the collectives called on RCCL directly (csrc/hsk_rccl.inc).
- * The phase functions above leave the collectives to the caller (hassaku_amd/dist.py: torch.distributed), which costs
- * ten host dispatches per step; hsk_shard_step enqueues the same kernels and ncclAllGather / ncclAllReduce /
- * ncclReduceScatter between them -- the row exchanges on a communication stream, so that the preparation of the next
- * batch and the item pass overlap them.  Same results as the phased sequence.  RCCL is loaded at run time (dlopen).
+ * The sharded step issued from ONE C call, its collectives called through a table of function pointers
+ * (csrc/hsk_rccl.inc).  The phase functions above leave the collectives to the caller (hassaku_amd/dist.py:
+ * torch.distributed), which costs ten host dispatches per step; hsk_shard_step enqueues the same kernels and the
+ * collectives between them -- the gradients' way home on a communication stream, so that the item pass overlaps it.
+ * Same results as the phased sequence.  Replaces, with everything above, nn.DataParallel (train/trainer.py:38-41).
+ *
+ * The table: float32 collectives over the job's ranks, enqueued on `stream` in stream order, 0 on success.
+ *   all_gather(send [count] -> recv [world*count])   all_reduce_sum(buf [count], in place)
+ *   reduce_scatter_sum(send [world*count] -> recv [count] = sum over ranks of their send[rank*count ..])
+ * Built in: RCCL (loaded at run time by dlopen; hsk_rccl_unique_id) and a HOST-STAGED table for ranks that are
+ * processes sharing ONE GPU (hsk_hostcoll_unique_id: shared memory + host functions on the stream; a test backend --
+ * RCCL refuses two ranks on one device -- so that hsk_shard_step itself runs at world > 1 on a one-GPU box).
  *   hsk_rccl_available      1 if librccl could be loaded
  *   hsk_rccl_unique_id      rank 0: 128 bytes (host) that the caller hands to every rank by any transport
- *   hsk_shard_rt_create     collective: every rank, same 128 bytes, its GPU current -> runtime handle (communicator,
- *                           side / communication streams, the batch prepared a step ahead), NULL on failure
+ *   hsk_hostcoll_unique_id  rank 0: the same for the host-staged table; max_floats = the largest per-rank send of one
+ *                           collective (world * capacity * dim for the step)
+ *   hsk_shard_rt_create     collective: every rank, same 128 bytes (either kind), its GPU current -> runtime handle
+ *                           (the collectives, side / communication streams, the batch prepared a step ahead), or NULL
+ *   hsk_shard_rt_create_with  the same around a caller-provided table (ctx is owned by the handle from then on)
+ *   hsk_shard_rt_backend    "rccl", "host-staged" or the injected table's name
  *   hsk_shard_step          one global step; next_start >= 0 names the following call's batch (prepared a step ahead;
- *                           next_batch <= 0: same size); replaces pack .. apply_users of the phased protocol
+ *                           next_batch <= 0: same size); replaces pack .. apply_users of the phased protocol.  Every
+ *                           argument is validated before anything is enqueued; a later failure joins the forked streams
+ *                           back and leaves the state idle (phase, prepared batch dropped)
  *   hsk_shard_rt_flush      drops a prepared batch that was never trained on, then hsk_shard_flush
  *   hsk_shard_rt_cur_set / _discard_prefetch   debug / parity (which buffer set the last step used)
  * ------------------------------------------------------------------------------------------ */
+typedef struct hsk_collectives {
+  void* ctx;
+  int (*all_gather)(void* ctx, const float* send, float* recv, int64_t count, hsk_stream_t stream);
+  int (*all_reduce_sum)(void* ctx, float* buf, int64_t count, hsk_stream_t stream);
+  int (*reduce_scatter_sum)(void* ctx, const float* send, float* recv, int64_t count, hsk_stream_t stream);
+  void (*destroy)(void* ctx);   /* may be NULL */
+  const char* name;             /* static string */
+} hsk_collectives;
+
 int hsk_rccl_available(void);
 int hsk_rccl_unique_id(void* id128);
+int hsk_hostcoll_unique_id(int64_t max_floats, void* id128);
 void* hsk_shard_rt_create(int32_t world, int32_t rank, const void* id128);
+void* hsk_shard_rt_create_with(int32_t world, int32_t rank, const hsk_collectives* coll);
+const char* hsk_shard_rt_backend(const void* rt);
 void hsk_shard_rt_destroy(void* rt);
 int hsk_shard_step(hsk_bprmf_shard* sh, void* rt, const int64_t* order, int64_t start_global, int64_t batch,
                    int64_t n_neg, int64_t next_start, int64_t next_batch, hsk_stream_t stream);

@@ -65,7 +65,7 @@ def _softplus(z):
     return np.maximum(z, 0) + np.log1p(np.exp(-np.abs(z)))
 
 
-def _cpu_protocol_worker(rank, world, port, out_dir):
+def _cpu_protocol_worker(rank, world, port, out_dir, loss='bpr'):
     _init(rank, world, port)
     from hassaku_amd.dist import Comm, item_range, local_user_count, user_capacity
     from oracle import oracle as orc
@@ -73,6 +73,7 @@ def _cpu_protocol_worker(rank, world, port, out_dir):
     rng = np.random.RandomState(0)                      # same stream on every rank
     U, I, D, B, N, lr, wd = 37, 50, 16, 12, 5, 1e-2, 1e-3
     G = world * B
+    log_adjust = float(np.log(I / N)) if loss == 'sampled_softmax' else 0.0
     Ufull = (rng.randn(U, D) * 0.1).astype(np.float32)
     Ifull = (rng.randn(I, D) * 0.1).astype(np.float32)
     Ibfull = (rng.randn(I) * 0.1).astype(np.float32)
@@ -82,8 +83,9 @@ def _cpu_protocol_worker(rank, world, port, out_dir):
     assert Uloc.shape[0] == local_user_count(U, rank, world)
     mU, vU = np.zeros_like(Uloc), np.zeros_like(Uloc)
     mI, vI, mIb, vIb = np.zeros_like(Iloc), np.zeros_like(Iloc), np.zeros_like(Ibloc), np.zeros_like(Ibloc)
-    ref = orc.MfOracleTrainer(Ufull, Ifull, Ibfull, lr=lr, wd=wd) if rank == 0 else None
+    ref = orc.MfOracleTrainer(Ufull, Ifull, Ibfull, lr=lr, wd=wd, loss=loss, log_adjust=log_adjust) if rank == 0 else None
     losses = []
+    n_coll = {'s0': 0, 'gsum': 0, 'ssm': 0}
     for step in range(1, 5):
         gu = rng.randint(0, U, size=G).astype(np.int64)                    # the GLOBAL batch, known to all
         gu[1] = gu[0]                                                       # duplicate users, also across slices
@@ -102,33 +104,82 @@ def _cpu_protocol_worker(rank, world, port, out_dir):
         s0 = np.zeros(G, np.float32)
         own_pos = mine[:, 0]
         s0[own_pos] = (Ub[own_pos] * Iloc[gi[own_pos, 0] - lo]).sum(-1) + Ibloc[gi[own_pos, 0] - lo]
-        s0_t = torch.from_numpy(s0)
-        comm.all_reduce(s0_t)
-        s0 = s0_t.numpy()
-        # owned negatives: weights, partial user-row gradients, partial weight sums, partial loss
-        inv = np.float32(1.0 / (G * N))
+        if loss == 'bpr':                                                   # bce: the owner's own s0 is all it needs
+            s0_t = torch.from_numpy(s0)
+            comm.all_reduce(s0_t)
+            s0 = s0_t.numpy()
+            n_coll['s0'] += 1
+        inv = np.float32({'bpr': 1.0 / (G * N), 'bce': 1.0 / (G * (N + 1)), 'sampled_softmax': 1.0 / G}[loss])
         dU = np.zeros((world * C, D), np.float32)
         gsum = np.zeros(G, np.float32)
         gI, gIb = np.zeros_like(Iloc), np.zeros_like(Ibloc)
         loss_part = 0.0
         g_entry = np.zeros((G, N + 1), np.float32)
+        m_r = np.full(G, -np.inf, np.float32)
+        l_r = np.zeros(G, np.float32)
+        z_entry = np.zeros((G, N + 1), np.float32)
+        # owned negatives: weights, partial user-row gradients, partial sums, partial loss
         for b in range(G):
-            for k in range(1, N + 1):
-                if not mine[b, k]:
-                    continue
+            ks = [k for k in range(1, N + 1) if mine[b, k]]
+            sc = {k: np.float32(np.dot(Ub[b], Iloc[gi[b, k] - lo]) + Ibloc[gi[b, k] - lo]) for k in ks}
+            if loss == 'sampled_softmax' and ks:
+                z = {k: np.float32(sc[k] + log_adjust) for k in ks}
+                m_r[b] = max(z.values())
+                for k in ks:
+                    e = np.exp(z[k] - m_r[b])
+                    l_r[b] += e
+                    dU[slot_of_b[b]] += e * Iloc[gi[b, k] - lo]            # unnormalised, scaled below
+                    z_entry[b, k] = z[k]
+            for k in ks:
                 j = gi[b, k] - lo
-                x = s0[b] - (np.dot(Ub[b], Iloc[j]) + Ibloc[j])
-                g = inv / (1.0 + np.exp(x))
+                if loss == 'bpr':
+                    x = s0[b] - sc[k]
+                    g = inv / (1.0 + np.exp(x))
+                    gsum[b] += g
+                    loss_part += _softplus(-x)
+                elif loss == 'bce':
+                    g = inv / (1.0 + np.exp(-sc[k]))
+                    loss_part += _softplus(sc[k])
+                else:
+                    continue
                 g_entry[b, k] = g
-                gsum[b] += g
                 dU[slot_of_b[b]] += g * Iloc[j]
-                loss_part += _softplus(-x)
-        gs_t = torch.from_numpy(gsum)
-        comm.all_reduce(gs_t)
-        gsum = gs_t.numpy()
-        for b in np.nonzero(own_pos)[0]:
-            g_entry[b, 0] = -gsum[b]
-            dU[slot_of_b[b]] += -gsum[b] * Iloc[gi[b, 0] - lo]
+        if loss == 'bpr':
+            gs_t = torch.from_numpy(gsum)
+            comm.all_reduce(gs_t)
+            gsum = gs_t.numpy()
+            n_coll['gsum'] += 1
+            for b in np.nonzero(own_pos)[0]:
+                g_entry[b, 0] = -gsum[b]
+                dU[slot_of_b[b]] += -gsum[b] * Iloc[gi[b, 0] - lo]
+        elif loss == 'bce':
+            for b in np.nonzero(own_pos)[0]:
+                g0 = -inv / (1.0 + np.exp(s0[b]))
+                g_entry[b, 0] = g0
+                dU[slot_of_b[b]] += g0 * Iloc[gi[b, 0] - lo]
+                loss_part += _softplus(-s0[b])
+        else:
+            # one all_gather of the (max, normaliser, s0) triples in place of the two reductions
+            trip = torch.from_numpy(np.concatenate([m_r, l_r, s0]))
+            all_t = torch.empty(world * 3 * G)
+            comm.all_gather_into(all_t, trip)
+            n_coll['ssm'] += 1
+            t = all_t.numpy().reshape(world, 3, G)
+            s0g = t[:, 2, :].sum(0)
+            M = np.maximum(t[:, 0, :].max(0), s0g)
+            with np.errstate(invalid='ignore'):
+                L = np.exp(s0g - M) + (t[:, 1, :] * np.exp(t[:, 0, :] - M)).sum(0)
+            for b in range(G):
+                scale = (np.exp(m_r[b] - M[b]) if np.isfinite(m_r[b]) else 0.0) * inv / L[b]
+                dU[slot_of_b[b]] *= np.float32(scale)
+                for k in range(1, N + 1):
+                    if mine[b, k]:
+                        g_entry[b, k] = np.exp(z_entry[b, k] - M[b]) * inv / L[b]
+                if own_pos[b]:
+                    g0 = np.exp(s0g[b] - M[b]) * inv / L[b] - inv
+                    g_entry[b, 0] = g0
+                    dU[slot_of_b[b]] += g0 * Iloc[gi[b, 0] - lo]
+                    loss_part += -s0g[b] + M[b] + np.log(L[b])
         grads_mine = torch.empty((C, D))
         comm.reduce_scatter(grads_mine, torch.from_numpy(dU))
         # local item gradient (never leaves the rank) + AdamW on the shard
@@ -145,11 +196,14 @@ def _cpu_protocol_worker(rank, world, port, out_dir):
             if req[rank][s] >= 0:
                 gloc[req[rank][s]] += grads_mine.numpy()[s]
         orc.adamw_step(Uloc, gloc, mU, vU, lr, wd, step)
-        lt = torch.tensor([loss_part / (G * N)], dtype=torch.float64)
+        lt = torch.tensor([loss_part * float(inv)], dtype=torch.float64)
         comm.all_reduce(lt)
         losses.append(float(lt.item()))
         if ref is not None:
-            assert abs(ref.step(gu, gi)[0] - losses[-1]) < 1e-6 * abs(losses[-1])
+            assert abs(ref.step(gu, gi)[0] - losses[-1]) < 2e-6 * abs(losses[-1]), (loss, ref.step, losses)
+    # what each loss costs in scalar collectives per step (hassaku_hip.h, "Losses")
+    assert n_coll == {'bpr': {'s0': 4, 'gsum': 4, 'ssm': 0}, 'bce': {'s0': 0, 'gsum': 0, 'ssm': 0},
+                      'sampled_softmax': {'s0': 0, 'gsum': 0, 'ssm': 4}}[loss]
     pad = lambda a, n: np.pad(a, ((0, n - a.shape[0]),) + ((0, 0),) * (a.ndim - 1))
     parts = comm.all_gather(torch.from_numpy(pad(Uloc, local_user_count(U, 0, world))))
     n_max = max(item_range(I, r, world)[1] - item_range(I, r, world)[0] for r in range(world))
@@ -167,11 +221,14 @@ def _cpu_protocol_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_protocol_equals_unsharded_oracle(tmp_path):
+@pytest.mark.parametrize('loss', ['bpr', 'bce', 'sampled_softmax'])
+def test_sharded_protocol_equals_unsharded_oracle(tmp_path, loss):
+    """the three losses the reference's DataParallel wrap carries (train/rec_losses.py:27-139): bpr with its two scalar
+    reductions, bce with none, sampled softmax with one all_gather of (max, normaliser, s0) triples"""
     from conftest import assert_adam_param_close
     from oracle import oracle as orc
     orc.build()
-    mp.spawn(_cpu_protocol_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_cpu_protocol_worker, args=(2, _free_port(), str(tmp_path), loss), nprocs=2, join=True)
     r = np.load(os.path.join(str(tmp_path), 'res.npz'))
     assert_adam_param_close(r['U'], r['rU'], 'user_emb')
     assert_adam_param_close(r['I'], r['rI'], 'item_emb')
@@ -243,7 +300,11 @@ class _EvalDs:   # the attributes the evaluators read from a FullEvalDataset
         return {'label_indptr': lp, 'label_indices': li, 'excl_indptr': ep, 'excl_indices': ei}
 
 
-def _shard_worker(rank, world, port, out_dir, backend, shape, n_steps, lazy_items, prefetch):
+def _log_adjust(loss, I, N):
+    return float(np.log(I / N)) if loss == 'sampled_softmax' else 0.0
+
+
+def _shard_worker(rank, world, port, out_dir, backend, shape, n_steps, lazy_items, prefetch, native='auto', loss='bpr'):
     _init(rank, world, port, backend)
     torch.cuda.set_device(0)
     from conftest import csr_from_pairs
@@ -254,9 +315,16 @@ def _shard_worker(rank, world, port, out_dir, backend, shape, n_steps, lazy_item
     U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
     ptr, idx = csr_from_pairs(pairs, U)
     t = {k: _dev(v) for k, v in P.items()}
+    if loss == 'bce':
+        t['user_bias'] = None      # bce sends gradient to the user bias: not carried by the fused / sharded steps
     sh = ShardedBprMf(comm, t['user_emb'], t['item_emb'], t['item_bias'], t['user_bias'], None, lr=2e-3, wd=1e-4,
                       batch=B, n_neg=N, csr_indptr=_dev(ptr), csr_indices=_dev(idx), coo_user=_dev(pairs[:, 0], torch.int32),
-                      coo_item=_dev(pairs[:, 1], torch.int32), seed=77, lazy_items=lazy_items, prefetch=prefetch)
+                      coo_item=_dev(pairs[:, 1], torch.int32), seed=77, lazy_items=lazy_items, prefetch=prefetch,
+                      native=native, loss=loss, log_adjust=_log_adjust(loss, I, N))
+    if native == 'host-staged':
+        assert sh.issued_natively and sh.backend() == 'host-staged'   # hsk_shard_step itself, not the phased sequence
+    elif native is False:
+        assert not sh.issued_natively
     order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
     G = world * B
     n_slices = len(pairs) // G
@@ -279,24 +347,28 @@ def _shard_worker(rank, world, port, out_dir, backend, shape, n_steps, lazy_item
     metrics = evaluate_item_sharded(comm, sh, ds, ev, chunk=64)
     np.savez(os.path.join(out_dir, f'kept{rank}.npz'), offs=offs, items=items, ug=ug, lo=sh.item_lo, hi=sh.item_hi)
     if rank == 0:
-        np.savez(os.path.join(out_dir, 'mp.npz'), U=full_u.cpu().numpy(), Ub=full_ub.cpu().numpy(),
+        np.savez(os.path.join(out_dir, 'mp.npz'), U=full_u.cpu().numpy(),
+                 Ub=np.zeros(U, np.float32) if full_ub is None else full_ub.cpu().numpy(),
                  I=full_i.cpu().numpy(), Ib=full_ib.cpu().numpy(), losses=np.array(losses),
                  metric_names=np.array(sorted(metrics)), metric_values=np.array([metrics[k] for k in sorted(metrics)]))
+    sh.close()
     dist.destroy_process_group()
 
 
-def _single_gpu_reference(world, shape, n_steps, lazy_items='auto'):
+def _single_gpu_reference(world, shape, n_steps, lazy_items='auto', loss='bpr'):
     """The same global batches through the single-GPU fused step: same seed / order / step numbering -> same samples."""
     from conftest import csr_from_pairs
     from hassaku_amd import hip_ops as ops
     U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
     ptr, idx = csr_from_pairs(pairs, U)
     t = {k: _dev(v) for k, v in P.items()}
+    if loss == 'bce':
+        t['user_bias'] = None
     G = world * B
     st = ops.BprMfFusedState(t['user_emb'], t['item_emb'], t['item_bias'], t['user_bias'], None, lr=2e-3, wd=1e-4,
                              max_batch=G, max_cols=N + 1, seed=77, csr_indptr=_dev(ptr), csr_indices=_dev(idx),
                              coo_user=_dev(pairs[:, 0], torch.int32), coo_item=_dev(pairs[:, 1], torch.int32),
-                             lazy_items=lazy_items)
+                             lazy_items=lazy_items, loss=loss, log_adjust=_log_adjust(loss, I, N))
     order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
     n_slices = len(pairs) // G
     losses, batches = [], []
@@ -312,11 +384,12 @@ def _single_gpu_reference(world, shape, n_steps, lazy_items='auto'):
     return t, np.array(losses), lu.cpu().numpy(), li.cpu().numpy(), batches
 
 
-def _oracle_replay(shape, batches):
+def _oracle_replay(shape, batches, loss='bpr'):
     """The same global batches through the CPU oracle (dense AdamW on every row, every step)."""
     from oracle import oracle as orc
     U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
-    tr = orc.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], P['user_bias'], None, lr=2e-3, wd=1e-4)
+    tr = orc.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], None if loss == 'bce' else P['user_bias'], None,
+                             lr=2e-3, wd=1e-4, loss=loss, log_adjust=_log_adjust(loss, I, N))
     losses = []
     for s, (u, it) in enumerate(batches):
         loss, _, _, _ = tr.step(u.astype(np.int64), it.astype(np.int64))
@@ -325,12 +398,13 @@ def _oracle_replay(shape, batches):
     return tr.P, np.array(losses)
 
 
-def _check_against_single_gpu(tmp_path, world, shape, n_steps):
+def _check_against_single_gpu(tmp_path, world, shape, n_steps, loss='bpr'):
     from conftest import assert_adam_param_close
     from hassaku_amd import hip_ops as ops
     from hassaku_amd.data.csr import UserItemCsr
     r = np.load(os.path.join(str(tmp_path), 'mp.npz'))
-    t, losses, lu, li, batches = _single_gpu_reference(world, shape, n_steps)
+    t, losses, lu, li, batches = _single_gpu_reference(world, shape, n_steps, loss=loss)
+    has_ub = loss != 'bce'
     U, I, D, B, N, pairs, P, val = _toy_problem(**shape)
     # the samples: each rank kept exactly the entries of the single-GPU batch that fall into its item range,
     # positive first, negatives in column order
@@ -343,17 +417,19 @@ def _check_against_single_gpu(tmp_path, world, shape, n_steps):
             assert list(k['items'][k['offs'][b]:k['offs'][b + 1]]) == want, (rank, b)
     np.testing.assert_allclose(r['losses'], losses, rtol=2e-5)
     assert_adam_param_close(r['U'], t['user_emb'].cpu().numpy(), 'user_emb')
-    assert_adam_param_close(r['Ub'], t['user_bias'].cpu().numpy(), 'user_bias')
+    if has_ub:
+        assert_adam_param_close(r['Ub'], t['user_bias'].cpu().numpy(), 'user_bias')
     assert_adam_param_close(r['I'], t['item_emb'].cpu().numpy(), 'item_emb')
     assert_adam_param_close(r['Ib'], t['item_bias'].cpu().numpy(), 'item_bias')
     # ... and DIRECTLY against the oracle: the batches above (each rank's kept entries were just shown to be exactly
     # their entries in its item range) replayed through the CPU restatement of the reference's dense step
-    oP, olosses = _oracle_replay(shape, batches)
+    oP, olosses = _oracle_replay(shape, batches, loss)
     np.testing.assert_allclose(r['losses'], olosses, rtol=2e-5)
     assert_adam_param_close(r['U'], oP['user_emb'], 'user_emb vs oracle')
     assert_adam_param_close(r['I'], oP['item_emb'], 'item_emb vs oracle')
     assert_adam_param_close(r['Ib'], oP['item_bias'], 'item_bias vs oracle')
-    assert_adam_param_close(r['Ub'], oP['user_bias'], 'user_bias vs oracle')
+    if has_ub:
+        assert_adam_param_close(r['Ub'], oP['user_bias'], 'user_bias vs oracle')
     # item-sharded evaluation == single-GPU evaluation of the gathered tables
     lab = UserItemCsr.from_pairs(val[:, 0], val[:, 1], U, I)
     exc = UserItemCsr.from_pairs(pairs[:, 0], pairs[:, 1], U, I)
@@ -361,7 +437,8 @@ def _check_against_single_gpu(tmp_path, world, shape, n_steps):
     ep, ei = exc.to_device('cuda')
     ks = [100, 50, 10, 5]
     u = torch.arange(U, device='cuda')
-    _, ids, _ = ops.mf_eval_topk(_dev(r['U']), _dev(r['I']), _dev(r['Ib']), _dev(r['Ub']), None, u, 100, ep, ei)
+    _, ids, _ = ops.mf_eval_topk(_dev(r['U']), _dev(r['I']), _dev(r['Ib']), _dev(r['Ub']) if has_ub else None, None, u, 100,
+                                 ep, ei)
     met = ops.rank_metrics(ids, u, lp, lix, ks).double().cpu().numpy()
     got = dict(zip([str(x) for x in r['metric_names']], r['metric_values']))
     grp = np.arange(U) % 2
@@ -382,9 +459,8 @@ def test_one_rank_rccl_sharded_step_equals_single_gpu_step(tmp_path):
 
 
 def _native_or_phased_worker(rank, world, port, out_dir, native):
-    os.environ['HSK_SHARD_NATIVE'] = '1' if native else '0'
     os.makedirs(out_dir, exist_ok=True)
-    _shard_worker(rank, world, port, out_dir, 'nccl', dict(D=64, N=12), 70, 'auto', True)
+    _shard_worker(rank, world, port, out_dir, 'nccl', dict(D=64, N=12), 70, 'auto', True, native)
 
 
 @pytest.mark.gpu
@@ -419,6 +495,122 @@ def test_three_rank_lazy_items_no_prefetch(tmp_path):
     shape = dict(D=402, N=7, U=97, I=1000, B=20)
     mp.spawn(_shard_worker, args=(3, _free_port(), str(tmp_path), 'gloo', shape, 66, True, False), nprocs=3, join=True)
     _check_against_single_gpu(tmp_path, 3, shape, 66)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,shape,n_steps,lazy_items,prefetch', [
+    (2, dict(D=64, N=12), 70, 'auto', True),
+    (3, dict(D=402, N=7, U=97, I=1000, B=20), 66, True, True),
+])
+def test_native_step_runs_multi_rank_over_host_staged_collectives(tmp_path, world, shape, n_steps, lazy_items, prefetch):
+    """hsk_shard_step ITSELF at world 2 and 3 on one GPU: the ranks are processes sharing cuda:0, the collective table is
+    the library's host-staged one (RCCL refuses two ranks of a communicator on one device).  What only shows at W >= 2 --
+    per-rank counts at C*D, the fork order, one collective table used from two streams, the batch prepared a step ahead
+    on the side stream, a wrong next-batch guess -- runs here and is held to the single-GPU step and to the oracle."""
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path), 'gloo', shape, n_steps, lazy_items, prefetch,
+                                  'host-staged'), nprocs=world, join=True)
+    _check_against_single_gpu(tmp_path, world, shape, n_steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('loss', ['bce', 'sampled_softmax'])
+@pytest.mark.parametrize('native', [False, 'host-staged'])
+def test_two_rank_sharded_step_other_losses(tmp_path, loss, native):
+    """bce (no scalar collective) and sampled softmax (one all_gather of (max, normaliser, s0) triples) through the sharded
+    step, phase by phase over gloo and from hsk_shard_step over the host-staged table: == the single-GPU fused step with the
+    same loss on the same global batches, and == the oracle's replay (train/rec_losses.py:27-53, :91-139)."""
+    shape = dict(D=64, N=12)
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path), 'gloo', shape, 40, 'auto', True, native, loss),
+             nprocs=2, join=True)
+    _check_against_single_gpu(tmp_path, 2, shape, 40, loss)
+
+
+def _overflow_worker(rank, world, port, out_dir, native):
+    _init(rank, world, port, 'gloo')
+    torch.cuda.set_device(0)
+    from conftest import csr_from_pairs
+    from hassaku_amd.dist import Comm, ShardedBprMf
+    comm = Comm()
+    U, I, D, B, N, pairs, P, val = _toy_problem(D=64, N=12)
+    ptr, idx = csr_from_pairs(pairs, U)
+    G = world * B
+    order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
+    n_slices = len(pairs) // G
+
+    def build(entry_cap):
+        t = {k: _dev(v) for k, v in P.items()}
+        return ShardedBprMf(comm, t['user_emb'], t['item_emb'], t['item_bias'], t['user_bias'], None, lr=2e-3, wd=1e-4,
+                            batch=B, n_neg=N, csr_indptr=_dev(ptr), csr_indices=_dev(idx),
+                            coo_user=_dev(pairs[:, 0], torch.int32), coo_item=_dev(pairs[:, 1], torch.int32), seed=77,
+                            lazy_items=False, prefetch=True, native=native, entry_cap=entry_cap)
+
+    def run(sh, n, name_next_of_last=True):
+        for s in range(n):
+            nxt = ((s + 1) % n_slices) * G if (s + 1 < n or name_next_of_last) else None
+            sh.step_sampled(order, (s % n_slices) * G, next_start=nxt)
+
+    def raw(sh):   # the shards as they sit in memory (no flush: lazily updated rows included as they are)
+        torch.cuda.synchronize()
+        return [x.clone() for x in (sh.user_emb, sh.item_emb, sh.item_bias, sh.user_bias, sh.m['user_emb'], sh.v['user_emb'],
+                                    sh.m['item_emb'], sh.v['item_emb'], sh.m['item_bias'], sh.v['item_bias'])]
+
+    # calibration: kept entries per step on this rank with ample room -> a capacity the first steps fit and a later one does not
+    sh = build(None)
+    kept = []
+    for s in range(40):
+        sh.step_sampled(order, (s % n_slices) * G)
+        kept.append(int(sh.last_batch()[0][-1].item()))
+    sh.close()
+    first_over = np.array([0], dtype=np.int64)
+    cap = 0
+    if rank == 0:
+        k = np.array(kept)
+        cap = int(k[:6].max())                       # steps 1..6 fit on rank 0 ...
+        later = np.nonzero(k[6:] > cap)[0]
+        assert len(later), 'calibration found no later, larger batch'
+        first_over[0] = 6 + int(later[0])            # ... this (0-based) step is rank 0's first that does not
+    t = torch.tensor([cap, int(first_over[0])], dtype=torch.int64)
+    dist.broadcast(t, src=0)
+    cap0, s_star = int(t[0]), int(t[1])
+    cap_r = cap0 if rank == 0 else None              # the other ranks keep ample room: ONE rank overflows
+    # run A: up to (not including) the overflowing step
+    a = build(cap_r)
+    run(a, s_star, name_next_of_last=False)      # (naming it would PREPARE the overflowing batch and flag the status word)
+    a.check_status()
+    before = raw(a)
+    a.close()
+    # run B: 300 steps; from the overflowing step on nothing may write a table, on ANY rank (the flag travels with the
+    # host check only, so the other ranks' guard is what this rank's skipped exchange leaves them: their own steps go on
+    # on stale but valid rows -- the job as a whole is dead and says so at the next check)
+    b = build(cap_r)
+    run(b, 300)
+    after = raw(b)
+    if rank == 0:
+        for x, y in zip(before, after):
+            assert torch.equal(x, y), 'a table changed after the first overflowing step'
+    b.flush()                                        # the sweep is guarded too
+    if rank == 0:
+        for x, y in zip(before, raw(b)):
+            assert torch.equal(x, y), 'the flush of a poisoned state wrote a table'
+    raised = False
+    try:
+        b.check_status()
+    except RuntimeError as e:
+        raised = 'capacity' in str(e) or 'another rank' in str(e)
+    assert raised, 'the overflow was not reported'
+    b.close()
+    open(os.path.join(out_dir, f'ok{rank}'), 'w').write(f'{cap0} {s_star}')
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('native', [False, 'host-staged'])
+def test_capacity_overflow_never_updates_a_table(tmp_path, native):
+    """entry_cap forced too small for ONE later batch of rank 0: 300 steps are issued without a host check; the rank's
+    tables (parameters and moments, as they sit in memory) are bit-equal to their state before the first overflowing step,
+    hsk_shard_flush included; check_status then raises on every rank.  (csrc/hsk_shard.inc: hsk_guard_skip.)"""
+    mp.spawn(_overflow_worker, args=(2, _free_port(), str(tmp_path), native), nprocs=2, join=True)
+    assert os.path.isfile(tmp_path / 'ok0') and os.path.isfile(tmp_path / 'ok1')
 
 
 @pytest.mark.gpu
