@@ -107,21 +107,68 @@ def build_state(data, D, B, N, device, seed=64, **kw):
     return st, csr
 
 
-def build_sharded_state(data, D, B, N, device, comm, seed=64):
+def build_sharded_state(data, D, B, N, device, comm, seed=64, native='auto', arrays=None):
     """world > 1: item table range-sharded, user table row-sharded (hassaku_amd/dist.py); B positives per rank."""
     from hassaku_amd.dist import ShardedBprMf
-    csr, arrays = device_interactions(data, device)
+    csr = None
+    if arrays is None:
+        csr, arrays = device_interactions(data, device)
     user_emb, item_emb, item_bias = init_tables(data.n_users, data.n_items, D, device, seed)   # same on every rank
-    st = ShardedBprMf(comm, user_emb, item_emb, item_bias, lr=LR, wd=WD, batch=B, n_neg=N, seed=seed, **arrays)
+    st = ShardedBprMf(comm, user_emb, item_emb, item_bias, lr=LR, wd=WD, batch=B, n_neg=N, seed=seed, native=native,
+                      **arrays)
     del user_emb, item_emb, item_bias
     return st, csr
+
+
+def native_step_self_check(data, D, B, N, device, comm, order, n_steps=3):
+    """Before a multi-rank job is timed: the natively issued step (hsk_shard_step, the library's own RCCL communicator,
+    collectives from C on two streams) against the phase-by-phase step (torch.distributed between the same kernels), from
+    the same initial state, on the job's own ranks and links.  -> dict(path, verdict, max_abs_diff).  'bit-equal' or
+    'equal within 1e-6 (reduction order)' lets the native path be timed; anything else fails the run on every rank."""
+    from hassaku_amd import _lib
+    if not (comm.native and _lib.load().hsk_rccl_available()):
+        return {'path': 'phased (torch.distributed)', 'verdict': 'native path not available', 'max_abs_diff': None}
+    csr, arrays = device_interactions(data, device)
+    G = B * comm.world
+    shards, losses = [], []
+    for native in (True, False):
+        st, _ = build_sharded_state(data, D, B, N, device, comm, native=native, arrays=arrays)
+        if native and not st.issued_natively:
+            return {'path': 'phased (torch.distributed)', 'verdict': 'hsk_shard_rt_create failed on a rank', 'max_abs_diff': None}
+        ls = []
+        for s in range(n_steps):
+            st.step_sampled(order, s * G, next_start=(s + 1) * G)
+            ls.append(st.last_loss())
+        st.flush()
+        st.check_status('native / phased self-check')
+        torch.cuda.synchronize()
+        shards.append([t.clone() for t in (st.user_emb, st.item_emb, st.item_bias, st.m['user_emb'], st.v['user_emb'],
+                                            st.m['item_emb'], st.v['item_emb'])])
+        losses.append(ls)
+        st.close()
+        del st
+        torch.cuda.empty_cache()
+    bit = all(torch.equal(a, b) for a, b in zip(*shards)) and losses[0] == losses[1]
+    worst = max(float((a - b).abs().max() / b.abs().max().clamp(min=1e-30)) for a, b in zip(*shards))
+    worst = max(worst, max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(*losses)))
+    flags = torch.tensor([0.0 if bit else 1.0, worst], dtype=torch.float64, device=device)
+    comm.all_reduce(flags, op='max')                 # every rank must see the same verdict
+    not_bit, worst = bool(flags[0].item()), float(flags[1].item())
+    if not not_bit:
+        verdict = 'bit-equal'
+    elif worst <= 1e-6:
+        verdict = 'equal within 1e-6 (reduction order)'
+    else:
+        verdict = 'MISMATCH'
+    return {'path': 'native (hsk_shard_step on RCCL)' if verdict != 'MISMATCH' else 'none', 'verdict': verdict,
+            'max_rel_diff': worst, 'steps_compared': n_steps}
 
 
 # ------------------------------------------------------------------------------------------------
 # one training workload
 # ------------------------------------------------------------------------------------------------
 def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy_users='auto', all_stages=False,
-                 pure_gather=True):
+                 pure_gather=True, strict=False):
     """-> dict(value, ms_per_step, fwd_us, fwd_launches, loss, B, N, D, data, csr, timing).  Timed exactly as the
     contract says: W warm-up steps, barrier + synchronize, K steps (+ the flush of lazily updated rows), barrier +
     synchronize; MAX over ranks."""
@@ -130,15 +177,25 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     world = 1 if comm is None else comm.world
     data = synthetic.generate_named(shape, seed=0)          # same seed on every rank: identical data everywhere
     nnz = data.train.shape[0]
-    if comm is None:
-        st, csr = build_state(data, D, B, N, device, overlap=prefetch, lazy_users=lazy_users)
-    else:
-        st, csr = build_sharded_state(data, D, B, N, device, comm)
     gen = torch.Generator(device=device)
     gen.manual_seed(64)
     order = torch.randperm(nnz, device=device, generator=gen)
     if comm is not None:
         comm.broadcast(order, src=0)                              # one epoch order for the whole job
+    self_check = None
+    if comm is None:
+        st, csr = build_state(data, D, B, N, device, overlap=prefetch, lazy_users=lazy_users)
+    else:
+        native = 'auto'
+        if world > 1:
+            # the natively issued step has to EARN being timed on this job's ranks: three steps against the phased path
+            self_check = native_step_self_check(data, D, B, N, device, comm, order)
+            if self_check['verdict'] == 'MISMATCH':
+                if comm.rank == 0:
+                    print(json.dumps({'error': 'native sharded step != phased sharded step', 'self_check': self_check}), flush=True)
+                raise SystemExit(3)
+            native = self_check['path'].startswith('native')
+        st, csr = build_sharded_state(data, D, B, N, device, comm, native=native)
     G = B * world
     n_batches = nnz // G
 
@@ -168,8 +225,10 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
         torch.cuda.synchronize()
 
     # (a short --warmup leaves the clocks, the caches and the prefetch pipeline cold: at least 32 untimed steps are run)
-    warmup_run = max(warmup, 32) if comm is None else warmup
-    if comm is None:
+    warmup_run = max(warmup, 32) if (comm is None and not strict) else warmup
+    if comm is None and strict:
+        run(warmup_run, 0)      # the driver's protocol to the letter: W warm-up steps, nothing else in front of the fence
+    elif comm is None:
         # ... and the lazily updated tables are swept two steps before the fence (a flush right at the fence would drop
         # the batch the last warm-up step prepared): the timed region starts with (almost) every row current and ends
         # with every row current -- it pays for its own steps' dense-AdamW work, not for the warm-up's backlog
@@ -191,7 +250,7 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
     if not replayed:
         # an event-timed launch costs the step ~10 us (measured: 210 / 206 / 202 us per step with every 1st / 2nd / 4th
         # step timed over 20 steps): every 4th step of a short run, every 8th of a long one
-        every = int(os.environ.get('HSK_BENCH_EVERY', 0)) or (1 if all_stages else 4 if steps <= 64 else 8)
+        every = int(os.environ.get('HSK_BENCH_EVERY', 0)) or (1 if all_stages else max(1, steps // 3) if steps <= 64 else 8)
         st.enable_timing(names if all_stages else ('fwd',), every=every)
     ev_f0, ev_f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
@@ -236,7 +295,10 @@ def run_training(workload, device, steps, warmup, comm=None, prefetch=True, lazy
                data=data, csr=csr, nnz=nnz, steps=steps, warmup=warmup, graph_replays=n_replays, pure_us=pure_us,
                flush_us=flush_us, flush_cadence=st.flush_cadence(B) if comm is None else st.flush_cadence(),
                lazy_users=bool(st.st.lazy_users) if comm is None else True,
-               parts=(st.batch_columns(B, N + 1) - N) if comm is None else 1, world=world, sharded=comm is not None)
+               parts=(st.batch_columns(B, N + 1) - N) if comm is None else 1, world=world, sharded=comm is not None,
+               pipelined_steps=st.pipelined_steps() if comm is None else 0, self_check=self_check,
+               step_issued_by=None if comm is None else st.backend() if st.issued_natively else 'python, phase by phase ('
+               + st.backend() + ')')
     if all_stages:
         out['stage_us_per_step'] = {k: v[0] * 1e3 / max(v[1], 1) for k, v in timing.items()}
     del st
@@ -283,6 +345,28 @@ def run_cfg5(device, steps, warmup, comm=None):
     if int(ok.item()) != (1 if share else W):
         raise RuntimeError(f'cfg5 build failed on rank {r}: {err}' if err is not None else 'cfg5 build failed on another rank')
     lazy_items = {'0': False, '1': True}.get(os.environ.get('HSK_CFG5_LAZY_ITEMS', ''), 'auto')   # (experiments)
+
+    def all_ok(flag, what):
+        """a failure on ONE rank must stop EVERY rank before the next collective (a lone rank that gives the leg up while its
+        peers sit in an all_gather hangs the whole line)"""
+        if share:
+            if not flag:
+                raise RuntimeError(what)
+            return
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        c.all_reduce(t)
+        if int(t.item()) != W:
+            raise RuntimeError(what + (' (this rank)' if not flag else ' (another rank)'))
+
+    # the moments are allocated here (2 x the tables): past the estimate above this is where a rank could still run dry --
+    # before the constructor's first collective, so every rank learns of it here
+    err = None
+    try:
+        probe = torch.empty(int(8.0 * D * (U / W + I / W) + 2e9), dtype=torch.uint8, device=device)
+        del probe
+    except Exception as e:   # noqa: BLE001
+        err = e
+    all_ok(err is None, f'cfg5: not enough HBM for the AdamW moments: {err}')
     st = ShardedBprMf(c, tabs['user_emb'], tabs['item_emb'], tabs['item_bias'], None, None, lr=LR, wd=WD, batch=B,
                       n_neg=N, seed=64, inputs_are_shards=True, n_users=U, n_items=I, lazy_items=lazy_items,
                       **data.device_arrays())
@@ -604,18 +688,40 @@ def cpu_baseline(headline, budget_s):
             'legs': legs}
 
 
-def child_bench(device, *args):
+def child_bench(device, *args, env_extra=None):
     """`python bench.py --cpu-budget 0 <args>` as a child process on the same GPU -> its JSON line."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-budget', '0'] + list(args)
     env = dict(os.environ, MASTER_PORT=os.environ.get('HSK_BENCH_CHILD_PORT', '29541'), RANK='0', WORLD_SIZE='1',
-               LOCAL_RANK=str(device.index or 0))
+               LOCAL_RANK=str(device.index or 0), **(env_extra or {}))
     torch.cuda.empty_cache()
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    except subprocess.TimeoutExpired as e:
+        tail = (e.stderr or b'')[-300:] if isinstance(e.stderr, (bytes, bytearray)) else str(e.stderr or '')[-300:]
+        raise RuntimeError(f'child bench killed at its 900 s limit; stderr tail: {tail!r}')
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     if p.returncode != 0 or not lines:
         raise RuntimeError(f'child bench failed (rc {p.returncode}): {p.stderr[-300:]}')
     return json.loads(lines[-1])
+
+
+def run_ieee_build_child(device, steps, warmup):
+    """What the default build's Adam arithmetic buys: the same step with libhassaku_hip_ieee.so (-DHSK_ADAM_IEEE=1: IEEE sqrt
+    and divisions in the optimiser, torch's own arithmetic bit for bit) in a child process, on configs[2] under the same
+    protocol and on the HBM-resident point.  The default build uses v_sqrt_f32 / v_rcp_f32 (1 ulp); both builds meet the
+    same parity bounds (tests/test_hip_parity.py::test_default_build_vs_ieee_build_on_golden_steps)."""
+    from hassaku_amd import _lib
+    ieee = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libhassaku_hip_ieee.so')
+    if not os.path.isfile(ieee):
+        raise RuntimeError('libhassaku_hip_ieee.so not built')
+    env = {'HSK_LIB_PATH': ieee}
+    a = child_bench(device, '--only', '--no-pure-gather', '--steps', str(steps), '--warmup', str(warmup), env_extra=env)
+    b = child_bench(device, '--only', '--no-pure-gather', '--workload', 'hbm', '--steps', '64', '--warmup', '16', env_extra=env)
+    return {'build': '-DHSK_ADAM_IEEE=1 (IEEE sqrt / divisions in every optimiser update and replay)',
+            'ml10m': {'ms_per_step': a['ms_per_step'], 'steps': steps, 'warmup': warmup, 'fwd_us': a['roofline']['avg_us'],
+                      'flush_us_in_timed_region': a['flush_us_in_timed_region']},
+            'hbm': {'ms_per_step': b['ms_per_step'], 'steps': 64, 'warmup': 16, 'fwd_us': b['roofline']['avg_us']}}
 
 
 def run_cfg5_share_child(device):
@@ -734,6 +840,7 @@ def main():
         # the multi-GPU code path on this one GPU (a 1-rank RCCL group: every kernel, every collective call and stream
         # hand-off of the sharded step, no link traffic): what the step costs before any xGMI link is involved
         children['sharded_1rank'] = guarded(run_sharded_1rank, args.workload, device)
+        children['ieee_build'] = guarded(run_ieee_build_child, device, args.steps, args.warmup)
     r = run_training(args.workload, device, args.steps, args.warmup, comm=comm, prefetch=not args.no_prefetch,
                      lazy_users=False if args.dense_users else True if args.lazy_users else 'auto',
                      all_stages=args.time_all_stages, pure_gather=not args.no_pure_gather)
@@ -748,7 +855,12 @@ def main():
                    'lr': LR, 'wd': WD, 'loss_last_step': r['loss'],
                    'user_adamw': 'lazy, exact' if r['lazy_users'] else 'dense sweep',
                    'steps_issued_as_replayed_graphs': 64 * r['graph_replays'],
-                   'warmup_steps_run': r['warmup']},
+                   'steps_with_in_launch_preparation': r['pipelined_steps'],
+                   'warmup_steps_run': r['warmup'],
+                   'protocol_note': 'at least 32 untimed steps run whatever --warmup says, and the lazily updated tables are '
+                                    'swept two steps before the fence (the timed region pays for its own dense-AdamW backlog, '
+                                    'not the warm-up\'s); `as_given_protocol` is the same workload with exactly --warmup '
+                                    'steps and nothing else in front of the fence'},
         # the closing sweep of the lazily updated tables is inside the timed region: ms_per_step carries 1/steps of it
         'flush_us_in_timed_region': r['flush_us'],
         'ms_per_step_without_closing_flush': r['ms_per_step'] - r['flush_us'] * 1e-3 / args.steps,
@@ -757,6 +869,9 @@ def main():
     }
     if comm is not None:
         out['roofline']['kernel'] = 'k_shard_fwd (gather of the owned negatives + scores + BPR + partial user-row grad)'
+        out['config']['step_issued_by'] = r['step_issued_by']
+        if r['self_check'] is not None:
+            out['config']['native_vs_phased_self_check'] = r['self_check']
     if 'stage_us_per_step' in r:
         out['stage_us_per_step'] = r['stage_us_per_step']
 
@@ -779,6 +894,14 @@ def main():
             out['eval'] = {s: run_eval(s, device) for s in ('ml10m', 'lfm2b')}
             out['workloads']['cfg5_shard'] = children['cfg5_shard']
             out['sharded_1rank'] = children['sharded_1rank']
+            out['ieee_build'] = children['ieee_build']
+            # the driver's protocol to the letter: exactly --warmup steps, no sweep in front of the fence
+            x = guarded(run_training, args.workload, device, args.steps, args.warmup, None, not args.no_prefetch, 'auto',
+                        False, False, True)
+            out['as_given_protocol'] = x if 'error' in x else {
+                'ms_per_step': x['ms_per_step'], 'value': x['value'], 'unit': 'triplets/s', 'steps': args.steps,
+                'warmup_steps_run': x['warmup'], 'flush_us_in_timed_region': x['flush_us'],
+                'note': 'cold clocks / caches and the warm-up\'s whole lazy-AdamW backlog are inside this timed region'}
         else:
             out['eval'] = {'lfm2b': run_eval('lfm2b', device, comm)}
             if 'cfg5' in children:

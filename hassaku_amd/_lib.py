@@ -109,6 +109,7 @@ SIGNATURES = {
     'hsk_bprmf_hint_after_run': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64]),
     'hsk_bprmf_hint_after_run_n': (c_int, [POINTER(HskBprmfState), c_void_p, c_int64, c_int64, c_int64, c_int64]),
     'hsk_bprmf_pipelined_steps': (c_int64, [POINTER(HskBprmfState)]),
+    'hsk_bprmf_set_pipeline': (None, [c_int]),
     'hsk_shard_workspace_bytes': (c_int64, [c_int64] * 4),
     'hsk_shard_init': (c_int, [POINTER(HskBprmfShard), c_void_p]),
     'hsk_shard_prepare': (c_int, [POINTER(HskBprmfShard), c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p]),

@@ -16,6 +16,7 @@
 // lists of a row.  Excluded (user, item) pairs become -inf exactly as in the reference (they can still appear in the
 // top k of a user with fewer than k admissible items, lowest item id first).
 #include "hsk_common.h"
+#include "hsk_gemm_wide.h"
 #include <stdlib.h>
 
 #include <algorithm>
@@ -503,6 +504,313 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
       int32_t id = 0x7fffffff;   // pad of a split that holds fewer than k items: sorts behind everything real
       if (j < keep) {
         const unsigned long long c = srt[wave][j];
+        v = fg_key2f((uint32_t)(c >> 32));
+        id = (int32_t)(~(uint32_t)c);
+      }
+      part_vals[dst + j] = v;
+      part_idx[dst + j] = id;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// =============================================================================================
+// The in-GEMM selection on the 256 x 256 / one-wave-per-SIMD core (hsk_gemm_wide.h)
+// =============================================================================================
+// Round 3 built this once with the 128 x 128 kernel's epilogue (a compare, an exclusion test and a possible append per
+// score, ~12 000 instructions per tile and wave) and measured it SLOWER than the 128 x 128 kernel: with one wave per SIMD
+// nothing covers the epilogue.  This one is lean where it has to be:
+//   filter   per accumulator register (= one row, this lane's FOUR columns of it): the four scores against the row's
+//            threshold, one ballot.  64 such sites per tile and wave; the common case ends there.
+//   enqueue  lanes that passed put (4 scores, row, column) into a per-wave LDS queue at ballot-ranked positions
+//            (no atomics, ~10 instructions for a site where any lane passed) -- the queue lives in the operand stages,
+//            which are idle during the epilogue.
+//   drain    after each band of 16 sites the wave walks its queue DENSELY, 64 entries at a time: exact re-test of each of
+//            the four scores, exclusion bit, slot from the row's LDS counter, the 8-byte candidate out to the row's slab.
+// The divergent part (which lanes pass where) thus costs a few instructions per site instead of an append path per site,
+// and the append path runs on full waves.  ~1 700 instructions per tile and wave in steady state against ~120 000 cycles
+// of MFMAs.  Candidates, thresholds, compactions (MSB-first radix select by one wave per row) and the final lists are the
+// 128 x 128 kernel's; every score sees the same MFMA sequence: values, ids and order are bit-identical
+// (test_fused_topk_equals_materialised_topk).
+#define FGW_CAP 640            // candidates a row can hold between two compactions: TRIG + one whole tile of 256 columns
+#define FGW_TRIG 384
+#define FGW_Q 1024             // queue entries per wave and band (16 sites x 64 lanes: can never overflow)
+#define FGW_STATE_BYTES (3 * 256 * 4 + 256 * 8 * 4)   // thr, cnt, ubias [256] + emask [256][8]
+#define FGW_LDS_BYTES (GEMM_W_LDS_BYTES + FGW_STATE_BYTES)
+static_assert(FGW_LDS_BYTES <= 160 * 1024, "LDS of k_score_topk_wide");
+static_assert(4 * FGW_Q * 20 + 4 * 256 * 4 + 4 * HSK_SEL_KMAX * 8 <= GEMM_W_LDS_BYTES, "queues + select scratch fit the idle stages");
+
+__global__ __launch_bounds__(256, 1) void k_score_topk_wide(
+    const float* __restrict__ Ib, const float* __restrict__ Ub, const float* __restrict__ gb, int n_users, int Dp,
+    const int64_t* __restrict__ u_idx, int n_rows, long long item_begin, int item_count, int tiles_per_split,
+    const int64_t* __restrict__ excl_indptr, const int32_t* __restrict__ excl_indices, int k, int n_splits,
+    unsigned long long* __restrict__ cand_ws, float* __restrict__ part_vals, int32_t* __restrict__ part_idx,
+    int32_t* status, const __bf16* __restrict__ Apl, const __bf16* __restrict__ Bpl, int a_rows, int b_rows) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 wlds[];
+  constexpr int BM = GEMM_W_BM, BN = GEMM_W_BN, TM = 4, TN = 4;
+  __bf16* As = wlds;
+  __bf16* Bs = wlds + 2 * GEMM_W_A_STAGE;
+  unsigned char* state = reinterpret_cast<unsigned char*>(wlds) + GEMM_W_LDS_BYTES;
+  float* thr = reinterpret_cast<float*>(state);               // [256] current k-th best score of the row
+  int* cnt = reinterpret_cast<int*>(state + 1024);            // [256] candidates the row holds
+  float* ubias = reinterpret_cast<float*>(state + 2048);      // [256]
+  uint32_t* emask = reinterpret_cast<uint32_t*>(state + 3072);   // [256][8] exclusion bits of the current tile
+  // during the epilogue / the compactions the operand stages are idle: queues and select scratch live there
+  unsigned char* idle = reinterpret_cast<unsigned char*>(wlds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  hsk_f32x4* qv = reinterpret_cast<hsk_f32x4*>(idle) + wave * FGW_Q;                    // 4 x 16 KB
+  int* qm = reinterpret_cast<int*>(idle + 4 * FGW_Q * 16) + wave * FGW_Q;               // 4 x 4 KB
+  unsigned int* hist = reinterpret_cast<unsigned int*>(idle + 4 * FGW_Q * 20) + wave * 256;   // 4 x 1 KB
+  unsigned long long* srt = reinterpret_cast<unsigned long long*>(idle + 4 * FGW_Q * 20 + 4 * 1024) + wave * HSK_SEL_KMAX;
+
+  const int n_row_blocks = (n_rows + BM - 1) / BM;
+  const int per_group = 8 * n_splits;
+  const int grp = blockIdx.x / per_group, rem = blockIdx.x - grp * per_group;
+  const int split = rem >> 3;
+  const int rb = grp * 8 + (rem & 7);
+  if (rb >= n_row_blocks) return;
+  const int m0 = rb * BM;
+  const int n_tiles = (item_count + BN - 1) / BN;
+  const int t_lo = split * tiles_per_split, t_hi = min(n_tiles, t_lo + tiles_per_split);
+  unsigned long long* __restrict__ cand = cand_ws + ((long long)rb * n_splits + split) * ((long long)BM * FGW_CAP);
+
+  // thread = row: its user, bias, threshold, and where its exclusion row starts for this split
+  long long e_p = 0, e_end = 0, e_next = 0x7fffffffffffffffll;
+  {
+    const int r = m0 + tid;
+    int u = 0;
+    if (r < n_rows) {
+      long long uu = u_idx[r];
+      if (uu < 0 || uu >= n_users) {
+        if (status) atomicOr(status, HSK_STATUS_BAD_INDEX);
+        uu = 0;
+      }
+      u = (int)uu;
+    }
+    ubias[tid] = Ub ? Ub[u] : 0.f;
+    thr[tid] = -INFINITY;
+    cnt[tid] = 0;
+    if (excl_indptr && r < n_rows) {
+      long long lo = excl_indptr[u];
+      const long long hi = excl_indptr[u + 1];
+      const long long first_col = item_begin + (long long)t_lo * BN;
+      long long l = lo, hh = hi;
+      while (l < hh) {
+        const long long mid = (l + hh) >> 1;
+        if (excl_indices[mid] < first_col)
+          l = mid + 1;
+        else
+          hh = mid;
+      }
+      e_p = l;
+      e_end = hi;
+      if (e_p < e_end) e_next = excl_indices[e_p];
+    }
+  }
+  const float gbv = gb ? gb[0] : 0.f;
+
+  constexpr int KPL = FGW_CAP / 64;   // keys per lane of a compaction
+  auto compact_row = [&](int rloc) {   // one wave, one row with n > k candidates: keep the best k, raise thr
+    const int n = cnt[rloc];
+    if (n <= k) return;
+    unsigned long long kv[KPL];
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+      const int j = lane + 64 * m;
+      kv[m] = (j < n) ? cand[(long long)rloc * FGW_CAP + j] : 0ull;
+    }
+    unsigned long long prefix = 0ull, pmask = 0ull;
+    int need = k;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hist[lane * 4 + q] = 0u;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int m = 0; m < KPL; ++m)
+        if (kv[m] != 0ull && (kv[m] & pmask) == prefix) atomicAdd(&hist[(unsigned)(kv[m] >> shift) & 255u], 1u);
+      __builtin_amdgcn_wave_barrier();
+      const unsigned c0 = hist[lane * 4], c1 = hist[lane * 4 + 1], c2 = hist[lane * 4 + 2], c3 = hist[lane * 4 + 3];
+      const int mine = (int)(c0 + c1 + c2 + c3);
+      int above = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_down(above, off, 64);
+        if (lane + off < 64) above += t;
+      }
+      above -= mine;
+      int found_digit = -1, found_need = 0;
+      {
+        int a3 = above, a2 = above + (int)c3, a1 = a2 + (int)c2, a0 = a1 + (int)c1;
+        if (a3 < need && need <= a3 + (int)c3) { found_digit = lane * 4 + 3; found_need = need - a3; }
+        else if (a2 < need && need <= a2 + (int)c2) { found_digit = lane * 4 + 2; found_need = need - a2; }
+        else if (a1 < need && need <= a1 + (int)c1) { found_digit = lane * 4 + 1; found_need = need - a1; }
+        else if (a0 < need && need <= a0 + (int)c0) { found_digit = lane * 4; found_need = need - a0; }
+      }
+      const unsigned long long who = __ballot(found_digit >= 0);
+      const int src = __builtin_ctzll(who);
+      const int digit = __shfl(found_digit, src, 64);
+      need = __shfl(found_need, src, 64);
+      prefix |= (unsigned long long)digit << shift;
+      pmask |= 0xffull << shift;
+    }
+    int base = 0;
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+      const bool keep = kv[m] >= prefix && kv[m] != 0ull;
+      const unsigned long long bm = __ballot(keep);
+      if (keep) cand[(long long)rloc * FGW_CAP + base + __popcll(bm & ((1ull << lane) - 1ull))] = kv[m];
+      base += __popcll(bm);
+    }
+    if (lane == 0) {
+      cnt[rloc] = k;
+      thr[rloc] = fg_key2f((uint32_t)(prefix >> 32));
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  hsk_w_f32x16 acc[TM][TN];
+  hsk_wide_stage stg;
+  hsk_wide_init(stg, tid);
+  const int NT = Dp / GEMM_W_BK;
+  const long long a_step = (long long)a_rows * 48, b_step = (long long)b_rows * 48;
+  const __bf16* a0 = Apl + (long long)m0 * 48;
+  // first tile of the split: k-tile 0 -> LDS stage 0, k-tile 1 -> registers
+  {
+    const __bf16* b0 = Bpl + (long long)t_lo * BN * 48;
+    hsk_wide_load(stg, a0, b0, tid);
+    hsk_wide_store(stg, As, Bs);
+    hsk_wide_load(stg, a0 + (NT > 1 ? a_step : 0), b0 + (NT > 1 ? b_step : 0), tid);
+  }
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    const int n0 = tile * BN;
+    const __bf16* b0 = Bpl + (long long)n0 * 48;
+    // exclusion bits of this tile (the row's sorted CSR is consumed as the tiles advance); read in the drains, behind
+    // the k loop's barriers
+    {
+      uint32_t* em = emask + tid * 8;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) em[w] = 0u;
+      const long long col_lo = item_begin + n0, col_hi = col_lo + BN;
+      while (e_next < col_hi) {
+        const int c = (int)(e_next - col_lo);
+        if (c >= 0) em[c >> 5] |= 1u << (c & 31);
+        ++e_p;
+        e_next = (e_p < e_end) ? (long long)excl_indices[e_p] : 0x7fffffffffffffffll;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    __syncthreads();   // stage 0 of this tile is in place (stored behind the previous tile's compactions)
+    hsk_wide_kloop(acc, stg, As, Bs, a0, b0, a_step, b_step, NT, tid, wm, wn, r32, h);
+    const bool more = tile + 1 < t_hi;
+    if (more) hsk_wide_load(stg, a0, b0 + (long long)BN * 48, tid);   // next tile's k-tile 0: in flight during the epilogue
+
+    // ---- epilogue: filter -> per-wave queue -> dense drain, band by band ---------------------------------------
+    float ibv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 128 + j * 32 + r32;
+      ibv[j] = (Ib && col < item_count) ? Ib[item_begin + col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float t[16], ub[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rloc = wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        t[q] = (m0 + rloc < n_rows) ? thr[rloc] : INFINITY;   // rows past n_rows: nothing passes
+        ub[q] = Ub ? ubias[rloc] : 0.f;
+      }
+      int qn = 0;   // wave-uniform queue fill
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        hsk_f32x4 o;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float x = acc[i][j][q];
+          if (Ub) x += ub[q];   // reference order: += u_bias, += i_bias, += global_bias
+          if (Ib) x += ibv[j];
+          if (gb) x += gbv;
+          o[j] = x;
+        }
+        const bool pass = !(o[0] < t[q]) || !(o[1] < t[q]) || !(o[2] < t[q]) || !(o[3] < t[q]);   // NaN passes (torch.topk)
+        const unsigned long long mask = __ballot(pass);
+        if (mask) {   // wave-uniform
+          if (pass) {
+            const int pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
+            qv[pos] = o;
+            qm[pos] = (wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) | ((wn * 128 + r32) << 16);
+          }
+          qn += __popcll(mask);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order
+      for (int e0 = 0; e0 < qn; e0 += 64) {
+        const int e = e0 + lane;
+        if (e < qn) {
+          const hsk_f32x4 o = qv[e];
+          const int meta = qm[e];
+          const int rloc = meta & 0xffff, cbase = meta >> 16;
+          const float tr = thr[rloc];
+          const uint32_t* em = emask + rloc * 8;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int cloc = cbase + j * 32;
+            float x = o[j];
+            if (!(x < tr) && n0 + cloc < item_count) {
+              if ((em[cloc >> 5] >> (cloc & 31)) & 1u) x = -INFINITY;
+              if (!(x < tr)) {
+                const int slot = atomicAdd(&cnt[rloc], 1);
+                cand[(long long)rloc * FGW_CAP + slot] =
+                    ((unsigned long long)fg_f2key(x) << 32) | (uint32_t)(~(uint32_t)(item_begin + n0 + cloc));
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();   // every append of this tile has its slot
+    {   // rows that the next tile could overflow: compact now (wave w owns rows 64 w .. 64 w + 63, one per lane)
+      const int fill = cnt[wave * 64 + lane];
+      unsigned long long due = __ballot(fill > FGW_TRIG);
+      while (due) {
+        const int rr = __builtin_ctzll(due);
+        due &= due - 1;
+        compact_row(wave * 64 + rr);
+      }
+    }
+    __syncthreads();   // queues and select scratch are dead: the stages may be refilled
+    if (more) {
+      const __bf16* b1 = b0 + (long long)BN * 48;
+      hsk_wide_store(stg, As, Bs);
+      hsk_wide_load(stg, a0 + (NT > 1 ? a_step : 0), b1 + (NT > 1 ? b_step : 0), tid);
+    }
+  }
+
+  // final: every row down to its k best, sorted, out to this split's slice of the partial lists
+  __syncthreads();
+  for (int rr = 0; rr < 64; ++rr) {
+    const int rloc = wave * 64 + rr;
+    const int row = m0 + rloc;
+    if (row >= n_rows) break;
+    compact_row(rloc);
+    const int keep = min(cnt[rloc], k);
+    for (int j = lane; j < HSK_SEL_KMAX; j += 64) srt[j] = (j < keep) ? cand[(long long)rloc * FGW_CAP + j] : 0ull;
+    fg_wave_bitonic_desc(srt, HSK_SEL_KMAX, lane);
+    const long long dst = ((long long)split * n_rows + row) * k;
+    for (int j = lane; j < k; j += 64) {
+      float v = -INFINITY;
+      int32_t id = 0x7fffffff;   // pad of a split that holds fewer than k items: sorts behind everything real
+      if (j < keep) {
+        const unsigned long long c = srt[j];
         v = fg_key2f((uint32_t)(c >> 32));
         id = (int32_t)(~(uint32_t)c);
       }

@@ -1262,11 +1262,14 @@ static bool hsk_pipe_plan(const hsk_bprmf_state* st, int64_t batch, int64_t n_ne
   return true;
 }
 
-// HSK_PIPE=0: the side-stream prefetch everywhere (A/B runs, and the reference the bit-equality tests hold the pipeline to)
+// HSK_PIPE=0 / hsk_bprmf_set_pipeline(0): the side-stream prefetch everywhere (A/B runs, and the reference the
+// bit-equality tests hold the pipeline to)
+static int hsk_pipe_switch = getenv("HSK_PIPE") ? atoi(getenv("HSK_PIPE")) : 1;
+extern "C" void hsk_bprmf_set_pipeline(int on) { hsk_pipe_switch = on ? 1 : 0; }
+
 static bool hsk_pipe_eligible(const hsk_bprmf_state* st, int64_t batch, int64_t n_neg) {
-  static const int env = getenv("HSK_PIPE") ? atoi(getenv("HSK_PIPE")) : 1;
   const hsk_aux* a = (const hsk_aux*)st->aux;
-  if (!env || !a || a->g_desc || st->ws_sharded || st->lazy_items) return false;
+  if (!hsk_pipe_switch || !a || a->g_desc || st->ws_sharded || st->lazy_items) return false;
   if (st->loss_kind != HSK_LOSS_BPR && st->loss_kind != HSK_LOSS_BCE) return false;
   if (st->timing && (st->timing_mask & ~(1 << HSK_STAGE_FWD))) return false;   // stage timing brackets the separate launches
   return hsk_pipe_plan(st, batch, n_neg, nullptr, nullptr, nullptr);

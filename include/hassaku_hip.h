@@ -349,6 +349,9 @@ int64_t hsk_bprmf_graph_replays(const hsk_bprmf_state* st);
 /* number of steps hsk_bprmf_train_steps has issued with the next batches' preparation riding in the steps' own launches
  * (large batches; 0 when every step used the side-stream prefetch) */
 int64_t hsk_bprmf_pipelined_steps(const hsk_bprmf_state* st);
+/* Process-wide switch of that in-launch preparation (1: on, the default; environment HSK_PIPE sets the initial value):
+ * off, every step prepares its next batch on the side stream.  Results are bit-identical either way. */
+void hsk_bprmf_set_pipeline(int on);
 
 /* Bring lazily-updated user / item rows up to st->step (no-op with dense updates); also drops a pending hint and a
  * prefetched batch that was never trained on (a flush ends a run of steps). */

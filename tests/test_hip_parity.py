@@ -471,6 +471,68 @@ def test_multi_step_call_equals_single_steps(ops, shape):
         assert np.array_equal(res[0][1][k], res[1][1][k]), k
 
 
+@pytest.mark.parametrize('lazy', [True, False])
+def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy):
+    """Large batches on the item-partitioned forward prepare the next two batches INSIDE the step's own launches (sampler
+    and the item sort's phases as extra workgroups of the forward / item-user kernels, csrc/hsk_fused.hip: hsk_pipe_step)
+    instead of five launches on a side stream.  Same draws, same sort, same arithmetic: tables, moments and losses equal
+    the side-stream path's bit for bit -- across runs chained by hint_after_run (two batches named, one, none, a WRONG
+    one), a single step issued through the other path in between, and a flush in the middle."""
+    n_users, n_items, D, B, N = 700, 6000, 256, 2048, 17
+    rng = np.random.RandomState(9)
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.02)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
+    n_pos = len(pairs)
+    n_total = 40
+    reps = -(-(n_total + 4) * B // n_pos)
+    order = torch.from_numpy(np.concatenate([np.random.RandomState(6 + r).permutation(n_pos) for r in range(reps)])).cuda()
+    lib = ops._lib.load()
+    res = []
+    try:
+        for pipelined in (True, False):
+            lib.hsk_bprmf_set_pipeline(1 if pipelined else 0)
+            st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                                 coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32),
+                                 lazy_users=lazy)
+            st.st.nnz = order.numel()
+            assert st.batch_columns(B, N + 1) == N + 2        # P = 2: the shape the pipeline is for
+            s = 0
+            st.hint_after_run(order, 7 * B, B, N, n_batches=2)
+            st.steps_sampled(order, s * B, 7, B, N); s += 7   # cold start, tail: two batches named
+            st.hint_after_run(order, 12 * B, B, N, n_batches=1)
+            st.steps_sampled(order, s * B, 5, B, N); s += 5   # continues on prepared batches; tail: one batch
+            st.steps_sampled(order, s * B, 3, B, N); s += 3   # tail: none
+            st.hint_after_run(order, 33 * B, B, N, n_batches=2)   # a WRONG guess: the next run starts elsewhere
+            st.steps_sampled(order, s * B, 4, B, N); s += 4
+            st.step_sampled(order, s * B, B, N); s += 1       # one step through the single-step path
+            st.hint_after_run(order, (s + 6) * B, B, N, n_batches=2)
+            st.steps_sampled(order, s * B, 6, B, N); s += 6
+            st.flush()                                        # drops the two prepared batches
+            losses_mid = st.pop_loss_sum()
+            st.steps_sampled(order, s * B, n_total - s, B, N)
+            st.flush()
+            st.check_status()
+            assert st.step_count == n_total
+            assert (st.pipelined_steps() == n_total - 1) if pipelined else (st.pipelined_steps() == 0)
+            mom = {'m_' + k: v.cpu().numpy().copy() for k, v in st.m.items() if v is not None}
+            mom.update({'v_' + k: v.cpu().numpy().copy() for k, v in st.v.items() if v is not None})
+            bu, bi = st.last_batch(B, N + 1)
+            res.append(({k: v.cpu().numpy().copy() for k, v in t.items()}, mom, (losses_mid, st.pop_loss_sum()),
+                        (bu.cpu().numpy(), bi.cpu().numpy())))
+    finally:
+        lib.hsk_bprmf_set_pipeline(1)
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][3][0], res[1][3][0]) and np.array_equal(res[0][3][1], res[1][3][1])
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    for k in res[0][1]:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+
+
 @pytest.mark.parametrize('shape', [
     # (n_users, n_items, D, B, K, popular): which of the item sorts the step picks
     (300, 3706, 32, 128, 51, False),    # k_sort_lds: <= 8192 entries, <= 4 per item on average (BASELINE configs[1] shape)
