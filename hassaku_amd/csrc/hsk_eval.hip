@@ -251,6 +251,10 @@ void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0,
                            int n_pad, int D, void* planes, hipStream_t stream) {
   hsk_eval_split_planes_k(src, idx, row0, n_src_rows, n_valid, n_pad, D, planes, stream, GEMM_BK);
 }
+void hsk_eval_split_planes16(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
+                             int n_pad, int D, void* planes, hipStream_t stream) {
+  hsk_eval_split_planes_k(src, idx, row0, n_src_rows, n_valid, n_pad, D, planes, stream, 16);
+}
 
 typedef unsigned hsk_vu32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 structs ends up in scratch)
 typedef float hsk_f32x4 __attribute__((ext_vector_type(4)));
@@ -1172,11 +1176,13 @@ extern "C" int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_
                             wide ? 16 : GEMM_BK);
     HSK_LAUNCH_CHECK();
     if (wide) {
-      static bool lds_set = false;
-      if (!lds_set) {
+      static bool lds_set[64] = {};   // per device: the opt-in for > 64 KB of dynamic LDS is a per-device attribute
+      int dev = 0;
+      HSK_HIP(hipGetDevice(&dev));
+      if (dev >= 0 && dev < 64 && !lds_set[dev]) {
         HSK_HIP(hipFuncSetAttribute((const void*)k_score_gemm_x3_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     GEMM_W_LDS_BYTES));
-        lds_set = true;
+        lds_set[dev] = true;
       }
       dim3 wgrid((unsigned)hsk_ceil_div(item_count, GEMM_W_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_W_BM));
       k_score_gemm_x3_wide<<<wgrid, 256, GEMM_W_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, (int)n_users,

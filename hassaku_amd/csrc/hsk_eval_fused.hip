@@ -22,6 +22,7 @@
 #include <algorithm>
 
 typedef float hsk_f32x16 __attribute__((ext_vector_type(16)));
+typedef float hsk_f32x4 __attribute__((ext_vector_type(4)));
 
 #define FG_BM 128
 #define FG_X3_LDK 40   // = GEMM_X3_LDK of hsk_eval.hip: LDS row stride of a bf16 plane, in elements
@@ -540,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
 static_assert(FGW_LDS_BYTES <= 160 * 1024, "LDS of k_score_topk_wide");
 static_assert(4 * FGW_Q * 20 + 4 * 256 * 4 + 4 * HSK_SEL_KMAX * 8 <= GEMM_W_LDS_BYTES, "queues + select scratch fit the idle stages");
 
+// HAS_IB: item bias present; EXTRA: a user and / or global bias as well (the additions follow the reference's order and
+// are left out, not replaced by + 0, where a bias is absent: -0 + 0 would change a sign bit the materialised path keeps)
+template <bool HAS_IB, bool EXTRA>
 __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
     const float* __restrict__ Ib, const float* __restrict__ Ub, const float* __restrict__ gb, int n_users, int Dp,
     const int64_t* __restrict__ u_idx, int n_rows, long long item_begin, int item_count, int tiles_per_split,
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
       u = (int)uu;
     }
     ubias[tid] = Ub ? Ub[u] : 0.f;
-    thr[tid] = -INFINITY;
+    thr[tid] = r < n_rows ? -INFINITY : INFINITY;   // rows past n_rows: nothing ever passes (and nothing ever lowers it)
     cnt[tid] = 0;
     if (excl_indptr && r < n_rows) {
       long long lo = excl_indptr[u];
@@ -717,17 +721,18 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * 128 + j * 32 + r32;
-      ibv[j] = (Ib && col < item_count) ? Ib[item_begin + col] : 0.f;
+      ibv[j] = (HAS_IB && col < item_count) ? Ib[item_begin + col] : 0.f;
     }
+    // this lane's rows of band i: row_base + i * 32 + (q & 3) + 8 * (q >> 2) -- one base register, immediate offsets
+    const int row_base = wm * 128 + 4 * h;
+    const float* thr_b = thr + row_base;
+    const float* ub_b = ubias + row_base;
+    const int meta_base = row_base | ((wn * 128 + r32) << 16);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      float t[16], ub[16];
+      float t[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int rloc = wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        t[q] = (m0 + rloc < n_rows) ? thr[rloc] : INFINITY;   // rows past n_rows: nothing passes
-        ub[q] = Ub ? ubias[rloc] : 0.f;
-      }
+      for (int q = 0; q < 16; ++q) t[q] = thr_b[i * 32 + (q & 3) + 8 * (q >> 2)];
       int qn = 0;   // wave-uniform queue fill
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -735,9 +740,13 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           float x = acc[i][j][q];
-          if (Ub) x += ub[q];   // reference order: += u_bias, += i_bias, += global_bias
-          if (Ib) x += ibv[j];
-          if (gb) x += gbv;
+          if (EXTRA) {   // reference order: += u_bias, += i_bias, += global_bias
+            if (Ub) x += ub_b[i * 32 + (q & 3) + 8 * (q >> 2)];
+            if (HAS_IB) x += ibv[j];
+            if (gb) x += gbv;
+          } else if (HAS_IB) {
+            x += ibv[j];
+          }
           o[j] = x;
         }
         const bool pass = !(o[0] < t[q]) || !(o[1] < t[q]) || !(o[2] < t[q]) || !(o[3] < t[q]);   // NaN passes (torch.topk)
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
           if (pass) {
             const int pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
             qv[pos] = o;
-            qm[pos] = (wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) | ((wn * 128 + r32) << 16);
+            qm[pos] = meta_base + (i * 32 + (q & 3) + 8 * (q >> 2));
           }
           qn += __popcll(mask);
         }
@@ -863,12 +872,16 @@ __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ v
 // the pre-pass of MODE 2 / 3 (hsk_eval.hip, k_split_planes): pieces laid out [k-tile][row][piece][32]
 void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
                            int n_pad, int D, void* planes, hipStream_t stream);
+// ... laid out [k-tile of 16][row][piece][16]: what the 256 x 256 core reads
+void hsk_eval_split_planes16(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
+                             int n_pad, int D, void* planes, hipStream_t stream);
 
 // bytes of the pre-split pieces of a call (MODE 2 / 3)
 static int64_t hsk_fused_plane_bytes(int64_t n_rows, int64_t item_count, int64_t dim) {
   if (dim <= 0) return 0;
   const int64_t Dp = hsk_align_up(dim, FG_BK);
-  const int64_t a_rows = hsk_ceil_div(n_rows, FG_BM) * FG_BM, b_rows = hsk_ceil_div(item_count, FG_BN) * FG_BN;
+  // (rows padded to 256: what the 256 x 256 core reads; the 128 x 128 kernels need 128)
+  const int64_t a_rows = hsk_align_up(n_rows, GEMM_W_BM), b_rows = hsk_align_up(item_count, GEMM_W_BN);
   return hsk_align_up(3 * a_rows * Dp * 2, 256) + hsk_align_up(3 * b_rows * Dp * 2, 256);
 }
 
@@ -886,13 +899,36 @@ static int hsk_fused_splits(int64_t n_rows, int64_t item_count, int64_t k) {
   return (int)s;
 }
 
+// The 256 x 256 kernel: ONE workgroup per CU, so 256 of them are a full round.  Splits of the catalogue for it, or 0 when
+// the call is not for it (too few tiles per split: a split's first tiles are all warm-up -- every score passes until the
+// rows hold k candidates).  HSK_FUSED_WIDE: 0 never, 2 whenever the shape allows, 1 (default) by this rule.
+static int hsk_fused_wide_splits(int64_t n_rows, int64_t item_count, int64_t k) {
+  static const int wide_on = getenv("HSK_FUSED_WIDE") ? atoi(getenv("HSK_FUSED_WIDE")) : 1;
+  if (!wide_on) return 0;
+  const int64_t row_blocks = hsk_ceil_div(n_rows, GEMM_W_BM), n_tiles = hsk_ceil_div(item_count, GEMM_W_BN);
+  static const int target_wgs = getenv("HSK_FUSED_WIDE_WGS") ? atoi(getenv("HSK_FUSED_WIDE_WGS")) : 256;
+  int64_t s = std::max<int64_t>(1, target_wgs / row_blocks);
+  s = std::min<int64_t>(s, 4096 / std::max<int64_t>(k, 1));
+  const int64_t min_tiles = wide_on == 2 ? 2 : 16;
+  s = std::min<int64_t>(s, std::max<int64_t>(1, n_tiles / min_tiles));
+  if (s >= 8) s = s / 8 * 8;
+  if (wide_on != 2 && (n_tiles / s < min_tiles || row_blocks * s < 128)) return 0;   // (less than half a round)
+  return (int)s;
+}
+
+// candidate slabs + partial lists of one layout
+static int64_t hsk_fused_sel_bytes(int64_t n_rows, int64_t k, int64_t s, int64_t bm, int64_t cap) {
+  const int64_t row_blocks = hsk_ceil_div(n_rows, bm);
+  return hsk_align_up(row_blocks * s * bm * cap * 8, 256) + hsk_align_up(s * n_rows * k * 8, 256) + 256;
+}
+
 extern "C" int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count, int64_t k) {
   if (n_rows <= 0 || item_count <= 0 || k <= 0 || k > HSK_SEL_KMAX) return -1;
-  const int64_t s = hsk_fused_splits(n_rows, item_count, k);
-  const int64_t row_blocks = hsk_ceil_div(n_rows, FG_BM);
-  const int64_t slab = row_blocks * s * FG_BM * HSK_SEL_CAP * 8;   // candidate slabs
-  const int64_t parts = s * n_rows * k * 8;                         // partial (value, id) lists
-  return hsk_align_up(slab, 256) + hsk_align_up(parts, 256) + 256;
+  // (the larger of the two kernels' layouts: which one runs also depends on whether the pieces' scratch is there)
+  const int64_t narrow = hsk_fused_sel_bytes(n_rows, k, hsk_fused_splits(n_rows, item_count, k), FG_BM, HSK_SEL_CAP);
+  const int sw = hsk_fused_wide_splits(n_rows, item_count, k);
+  const int64_t wide = sw ? hsk_fused_sel_bytes(n_rows, k, sw, GEMM_W_BM, FGW_CAP) : 0;
+  return std::max(narrow, wide);
 }
 
 extern "C" int64_t hsk_mf_eval_fused_ws_bytes_dim(int64_t n_rows, int64_t item_count, int64_t k, int64_t dim) {
@@ -921,6 +957,58 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
   HSK_REQUIRE(ws_bytes >= need && ((uintptr_t)ws & 255) == 0, HSK_ERR_INVALID,
               "workspace: %lld bytes (256-byte aligned) needed, %lld given", (long long)need, (long long)ws_bytes);
   hipStream_t stream = (hipStream_t)stream_;
+  {
+    // the 256 x 256 / one-wave-per-SIMD kernel: needs the operands' pieces (k-tiles of 16) and enough tiles per split
+    static const int planes_on_w = getenv("HSK_EVAL_PLANES") ? atoi(getenv("HSK_EVAL_PLANES")) : 1;
+    const int SW = hsk_fused_wide_splits(n_rows, item_count, k);
+    const bool vec4w = (dim % 4 == 0) && ((((uintptr_t)user_emb | (uintptr_t)item_emb) & 15) == 0);
+    if (SW && hsk_eval_x3() && planes_on_w && planes_on_w != 3 && vec4w &&
+        ws_bytes >= need + hsk_fused_plane_bytes(n_rows, item_count, dim)) {
+      const int64_t row_blocks = hsk_ceil_div(n_rows, GEMM_W_BM), n_tiles = hsk_ceil_div(item_count, GEMM_W_BN);
+      const int tiles_per_split = (int)hsk_ceil_div(n_tiles, SW);
+      char* p = (char*)ws;
+      unsigned long long* slab = (unsigned long long*)p;
+      p += hsk_align_up(row_blocks * SW * GEMM_W_BM * FGW_CAP * 8, 256);
+      float* part_vals = (float*)p;
+      int32_t* part_idx = (int32_t*)(p + (int64_t)SW * n_rows * k * 4);
+      const int Dp = (int)hsk_align_up(dim, FG_BK);
+      const int a_rows = (int)(row_blocks * GEMM_W_BM), b_rows = (int)(n_tiles * GEMM_W_BN);
+      __bf16* Apl = (__bf16*)((char*)ws + need);
+      __bf16* Bpl = (__bf16*)((char*)Apl + hsk_align_up(3 * (int64_t)a_rows * Dp * 2, 256));
+      hsk_eval_split_planes16(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, Apl, stream);
+      hsk_eval_split_planes16(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, Bpl, stream);
+      HSK_LAUNCH_CHECK();
+      static bool lds_set[64] = {};   // per device: the opt-in for > 64 KB of dynamic LDS is a per-device attribute
+      int dev = 0;
+      HSK_HIP(hipGetDevice(&dev));
+      if (dev >= 0 && dev < 64 && !lds_set[dev]) {
+        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
+        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
+        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
+        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
+        lds_set[dev] = true;
+      }
+      const unsigned grid = (unsigned)(hsk_ceil_div(row_blocks, 8) * 8 * SW);
+#define HSK_TOPK_WIDE(IB, EX)                                                                                          \
+  k_score_topk_wide<IB, EX><<<grid, 256, FGW_LDS_BYTES, stream>>>(                                                     \
+      item_bias, user_bias, global_bias, (int)n_users, Dp, u_idx, (int)n_rows, (long long)item_begin, (int)item_count, \
+      tiles_per_split, excl_indptr, excl_indices, (int)k, SW, slab, SW == 1 ? out_vals : part_vals,                    \
+      SW == 1 ? out_idx : part_idx, status, Apl, Bpl, a_rows, b_rows)
+      const bool extra = user_bias || global_bias;
+      if (item_bias) { if (extra) HSK_TOPK_WIDE(true, true); else HSK_TOPK_WIDE(true, false); }
+      else           { if (extra) HSK_TOPK_WIDE(false, true); else HSK_TOPK_WIDE(false, false); }
+#undef HSK_TOPK_WIDE
+      HSK_LAUNCH_CHECK();
+      if (SW > 1) {
+        int npad = 1;
+        while (npad < SW * (int)k) npad <<= 1;
+        k_fused_merge<<<(unsigned)n_rows, 256, 0, stream>>>(part_vals, part_idx, SW, (int)n_rows, (int)k, npad, out_vals,
+                                                            out_idx);
+        HSK_LAUNCH_CHECK();
+      }
+      return HSK_OK;
+    }
+  }
   const int S = hsk_fused_splits(n_rows, item_count, k);
   const int64_t row_blocks = hsk_ceil_div(n_rows, FG_BM), n_tiles = hsk_ceil_div(item_count, FG_BN);
   const int tiles_per_split = (int)hsk_ceil_div(n_tiles, S);
@@ -945,7 +1033,7 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
                                                    status, ##__VA_ARGS__)
   if (planes) {
     const int Dp = (int)hsk_align_up(dim, FG_BK);
-    const int64_t a_rows = row_blocks * FG_BM, b_rows = n_tiles * FG_BN;
+    const int64_t a_rows = hsk_align_up(n_rows, GEMM_W_BM), b_rows = hsk_align_up(item_count, GEMM_W_BN);   // (as sized)
     __bf16* Apl = (__bf16*)((char*)ws + need);
     __bf16* Bpl = (__bf16*)((char*)Apl + hsk_align_up(3 * a_rows * Dp * 2, 256));
     const long long a_stride = a_rows * 96, b_stride = b_rows * 96;   // elements per k-tile
