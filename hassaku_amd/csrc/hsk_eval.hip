@@ -1213,6 +1213,47 @@ extern "C" int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_
   return HSK_OK;
 }
 
+// Threshold seeding for the in-GEMM selection (hsk_eval_fused.hip: k_score_topk_wide).  The k-th best score of a row
+// over ANY subset of the admissible items is a lower bound of its k-th best over all of them.  This scores the first
+// `sample_count` items of the range for every row (the 256 x 256 GEMM on the pieces the fused call has made anyway, the
+// exclusion mask, the row top-k) and leaves the k-th best as an ordered key in gthr[row]: the selection then starts with
+// a threshold only ~k / sample_count of the scores reach, instead of appending whole tiles until its lists fill.
+__global__ __launch_bounds__(256) void k_seed_keys(const float* __restrict__ vals, int n_rows, int k, uint32_t* __restrict__ gthr) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const uint32_t b = __float_as_uint(vals[(long long)r * k + k - 1]);
+  gthr[r] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // = fg_f2key of hsk_eval_fused.hip
+}
+
+int hsk_eval_seed_thresholds(const float* item_bias, const float* user_bias, const float* global_bias, int n_users, int Dp,
+                             const int64_t* u_idx, int n_rows, long long item_begin, int sample_count,
+                             const int64_t* excl_indptr, const int32_t* excl_indices, int k, const __bf16* Apl,
+                             const __bf16* Bpl, int a_rows, int b_rows, float* scores_ws, float* vals_ws, int32_t* idx_ws,
+                             uint32_t* gthr, int32_t* status, hipStream_t stream) {
+  static bool lds_set[64] = {};
+  int dev = 0;
+  HSK_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !lds_set[dev]) {
+    HSK_HIP(hipFuncSetAttribute((const void*)k_score_gemm_x3_wide, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_W_LDS_BYTES));
+    lds_set[dev] = true;
+  }
+  dim3 wgrid((unsigned)hsk_ceil_div(sample_count, GEMM_W_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_W_BM));
+  k_score_gemm_x3_wide<<<wgrid, 256, GEMM_W_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, n_users, Dp, u_idx, n_rows,
+                                                                 item_begin, sample_count, scores_ws, status, Apl, Bpl, a_rows,
+                                                                 b_rows);
+  HSK_LAUNCH_CHECK();
+  if (excl_indptr) {
+    k_mask_excluded<<<(unsigned)hsk_ceil_div(n_rows, 4), 256, 0, stream>>>(u_idx, n_rows, n_users, excl_indptr, excl_indices,
+                                                                          item_begin, sample_count, scores_ws);
+    HSK_LAUNCH_CHECK();
+  }
+  int rc = hsk_launch_topk_i32(scores_ws, n_rows, sample_count, sample_count, k, item_begin, vals_ws, idx_ws, stream);
+  if (rc) return rc;
+  k_seed_keys<<<(unsigned)hsk_ceil_div(n_rows, 256), 256, 0, stream>>>(vals_ws, n_rows, k, gthr);
+  HSK_LAUNCH_CHECK();
+  return HSK_OK;
+}
+
 extern "C" int hsk_topk_dense(const float* logits, int64_t rows, int64_t cols, int64_t ld, int64_t k, float* out_vals,
                               int64_t* out_idx, hsk_stream_t stream_) {
   HSK_REQUIRE(logits && out_vals && out_idx, HSK_ERR_INVALID, "NULL pointer argument");

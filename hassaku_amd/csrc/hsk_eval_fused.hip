@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
 // (test_fused_topk_equals_materialised_topk).
 #define FGW_CAP 640            // candidates a row can hold between two compactions: TRIG + one whole tile of 256 columns
 #define FGW_TRIG 384
-#define FGW_Q 1024             // queue entries per wave and band (16 sites x 64 lanes: can never overflow)
+#define FGW_Q 1536             // queue entries per wave: drained when it holds > 512 (a band adds at most 16 sites x 64 lanes)
 #define FGW_STATE_BYTES (3 * 256 * 4 + 256 * 8 * 4)   // thr, cnt, ubias [256] + emask [256][8]
 #define FGW_LDS_BYTES (GEMM_W_LDS_BYTES + FGW_STATE_BYTES)
 static_assert(FGW_LDS_BYTES <= 160 * 1024, "LDS of k_score_topk_wide");
@@ -549,7 +549,16 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
     const int64_t* __restrict__ u_idx, int n_rows, long long item_begin, int item_count, int tiles_per_split,
     const int64_t* __restrict__ excl_indptr, const int32_t* __restrict__ excl_indices, int k, int n_splits,
     unsigned long long* __restrict__ cand_ws, float* __restrict__ part_vals, int32_t* __restrict__ part_idx,
-    int32_t* status, const __bf16* __restrict__ Apl, const __bf16* __restrict__ Bpl, int a_rows, int b_rows) {
+    int32_t* status, const __bf16* __restrict__ Apl, const __bf16* __restrict__ Bpl, int a_rows, int b_rows,
+    uint32_t* __restrict__ gthr, int dbg, int pw) {
+  // pw: entries per row of this split's partial list: k (one split: the final, sorted list) or HSK_SEL_KMAX (several:
+  // k_fused_merge sorts the union anyway, so a row that ends with <= pw survivors is handed over as it is -- no select)
+  // gthr [n_rows] (zero-initialised keys): the best threshold any split has reached for the row.  A split's k-th best score
+  // so far is a lower bound of the row's k-th best over the whole catalogue, so every split may filter with the LARGEST
+  // of them: the splits of a row block run side by side (same XCD, one per CU) and would each warm up a list of their own
+  // -- 4 x k (1 + ln(n/4k)) appends per row instead of k (1 + ln(n/k)).  Published at the compactions (atomicMax), read at
+  // the head of every tile past this CU's L1; a stale value only filters less.  Lists may then end with fewer than k
+  // entries (padded with -inf, which the merge expects anyway); the merged top-k is exact whatever the thresholds were.
   extern __shared__ __attribute__((aligned(16))) __bf16 wlds[];
   constexpr int BM = GEMM_W_BM, BN = GEMM_W_BN, TM = 4, TN = 4;
   __bf16* As = wlds;
@@ -594,7 +603,9 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
       u = (int)uu;
     }
     ubias[tid] = Ub ? Ub[u] : 0.f;
-    thr[tid] = r < n_rows ? -INFINITY : INFINITY;   // rows past n_rows: nothing ever passes (and nothing ever lowers it)
+    // rows past n_rows: nothing ever passes (and nothing ever lowers it); the others start from the seeded lower bound
+    const uint32_t k0 = (gthr && r < n_rows) ? gthr[r] : 0u;   // (key 0: no bound yet)
+    thr[tid] = r < n_rows ? (k0 ? fg_key2f(k0) : -INFINITY) : INFINITY;
     cnt[tid] = 0;
     if (excl_indptr && r < n_rows) {
       long long lo = excl_indptr[u];
@@ -670,7 +681,10 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
     }
     if (lane == 0) {
       cnt[rloc] = k;
-      thr[rloc] = fg_key2f((uint32_t)(prefix >> 32));
+      const uint32_t kth = (uint32_t)(prefix >> 32);
+      const float told = thr[rloc], tnew = fg_key2f(kth);
+      thr[rloc] = (tnew < told) ? told : tnew;           // (the shared threshold may already be above this list's k-th)
+      if (gthr) atomicMax(&gthr[m0 + rloc], kth);
     }
     __builtin_amdgcn_wave_barrier();
   };
@@ -691,6 +705,12 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
   for (int tile = t_lo; tile < t_hi; ++tile) {
     const int n0 = tile * BN;
     const __bf16* b0 = Bpl + (long long)n0 * 48;
+    // the row's shared threshold, if another split has got further (read past the L1: agent-scope load)
+    if (gthr && m0 + tid < n_rows) {
+      const uint32_t ks = __hip_atomic_load(&gthr[m0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float ts = ks ? fg_key2f(ks) : -INFINITY;
+      if (thr[tid] < ts) thr[tid] = ts;
+    }
     // exclusion bits of this tile (the row's sorted CSR is consumed as the tiles advance); read in the drains, behind
     // the k loop's barriers
     {
@@ -728,12 +748,20 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
     const float* thr_b = thr + row_base;
     const float* ub_b = ubias + row_base;
     const int meta_base = row_base | ((wn * 128 + r32) << 16);
+    int qn = 0;   // wave-uniform queue fill (carried across the bands: drained when it runs high, and at the tile's end)
+    if (dbg & 1) {   // (timing experiments only: HSK_FUSED_DEBUG) keep the accumulators alive, select nothing
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][15];
+      if (sacc == 12345.678f) thr[tid] = sacc;
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float t[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) t[q] = thr_b[i * 32 + (q & 3) + 8 * (q >> 2)];
-      int qn = 0;   // wave-uniform queue fill
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         hsk_f32x4 o;
@@ -750,7 +778,7 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
           o[j] = x;
         }
         const bool pass = !(o[0] < t[q]) || !(o[1] < t[q]) || !(o[2] < t[q]) || !(o[3] < t[q]);   // NaN passes (torch.topk)
-        const unsigned long long mask = __ballot(pass);
+        const unsigned long long mask = (dbg & 4) ? (__ballot(pass) & 0ull) : __ballot(pass);   // (4: filter only)
         if (mask) {   // wave-uniform
           if (pass) {
             const int pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
@@ -761,6 +789,9 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
         }
       }
       __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order
+      if (dbg & 8) qn = 0;   // (8: filter + enqueue, no drain)
+      // one drain per tile in steady state (a few dozen entries); more often only while the thresholds are still low
+      if (qn <= 512 && i != TM - 1) continue;
       for (int e0 = 0; e0 < qn; e0 += 64) {
         const int e = e0 + lane;
         if (e < qn) {
@@ -784,6 +815,7 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
           }
         }
       }
+      qn = 0;
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();   // every append of this tile has its slot
@@ -810,12 +842,13 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
     const int rloc = wave * 64 + rr;
     const int row = m0 + rloc;
     if (row >= n_rows) break;
-    compact_row(rloc);
-    const int keep = min(cnt[rloc], k);
+    if (cnt[rloc] > pw) compact_row(rloc);
+    const int keep = min(cnt[rloc], pw);
     for (int j = lane; j < HSK_SEL_KMAX; j += 64) srt[j] = (j < keep) ? cand[(long long)rloc * FGW_CAP + j] : 0ull;
-    fg_wave_bitonic_desc(srt, HSK_SEL_KMAX, lane);
-    const long long dst = ((long long)split * n_rows + row) * k;
-    for (int j = lane; j < k; j += 64) {
+    if (n_splits == 1) fg_wave_bitonic_desc(srt, HSK_SEL_KMAX, lane);   // (several splits: k_fused_merge sorts the union)
+    else __builtin_amdgcn_wave_barrier();
+    const long long dst = ((long long)split * n_rows + row) * pw;
+    for (int j = lane; j < pw; j += 64) {
       float v = -INFINITY;
       int32_t id = 0x7fffffff;   // pad of a split that holds fewer than k items: sorts behind everything real
       if (j < keep) {
@@ -831,17 +864,20 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
 }
 
 // merge of the per-split lists: [n_parts, rows, k] -> [rows, k]  (same kernel contract as hsk_topk_merge)
+// pw: entries per row of a partial list (>= k: the 256 x 256 kernel hands over up to HSK_SEL_KMAX unsorted survivors)
 __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ vals, const int32_t* __restrict__ idx,
                                                      int n_parts, int rows, int k, int npad,
-                                                     float* __restrict__ out_vals, int32_t* __restrict__ out_idx) {
+                                                     float* __restrict__ out_vals, int32_t* __restrict__ out_idx,
+                                                     int pw = 0) {
   __shared__ unsigned long long cand[4096];
   const int r = blockIdx.x;
-  const int total = n_parts * k;
+  if (pw <= 0) pw = k;
+  const int total = n_parts * pw;
   for (int c = threadIdx.x; c < npad; c += 256) {
     unsigned long long v = 0ull;
     if (c < total) {
-      const int p = c / k, j = c - p * k;
-      const long long src = ((long long)p * rows + r) * k + j;
+      const int p = c / pw, j = c - p * pw;
+      const long long src = ((long long)p * rows + r) * pw + j;
       v = ((unsigned long long)fg_f2key(vals[src]) << 32) | (uint32_t)(~(uint32_t)idx[src]);
     }
     cand[c] = v;
@@ -872,6 +908,11 @@ __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ v
 // the pre-pass of MODE 2 / 3 (hsk_eval.hip, k_split_planes): pieces laid out [k-tile][row][piece][32]
 void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
                            int n_pad, int D, void* planes, hipStream_t stream);
+int hsk_eval_seed_thresholds(const float* item_bias, const float* user_bias, const float* global_bias, int n_users, int Dp,
+                             const int64_t* u_idx, int n_rows, long long item_begin, int sample_count,
+                             const int64_t* excl_indptr, const int32_t* excl_indices, int k, const __bf16* Apl,
+                             const __bf16* Bpl, int a_rows, int b_rows, float* scores_ws, float* vals_ws, int32_t* idx_ws,
+                             uint32_t* gthr, int32_t* status, hipStream_t stream);   // hsk_eval.hip
 // ... laid out [k-tile of 16][row][piece][16]: what the 256 x 256 core reads
 void hsk_eval_split_planes16(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
                              int n_pad, int D, void* planes, hipStream_t stream);
@@ -908,7 +949,7 @@ static int hsk_fused_wide_splits(int64_t n_rows, int64_t item_count, int64_t k) 
   const int64_t row_blocks = hsk_ceil_div(n_rows, GEMM_W_BM), n_tiles = hsk_ceil_div(item_count, GEMM_W_BN);
   static const int target_wgs = getenv("HSK_FUSED_WIDE_WGS") ? atoi(getenv("HSK_FUSED_WIDE_WGS")) : 256;
   int64_t s = std::max<int64_t>(1, target_wgs / row_blocks);
-  s = std::min<int64_t>(s, 4096 / std::max<int64_t>(k, 1));
+  s = std::min<int64_t>(s, 4096 / HSK_SEL_KMAX);   // the merge sorts <= 4096 keys per row, HSK_SEL_KMAX per split
   const int64_t min_tiles = wide_on == 2 ? 2 : 16;
   s = std::min<int64_t>(s, std::max<int64_t>(1, n_tiles / min_tiles));
   if (s >= 8) s = s / 8 * 8;
@@ -916,10 +957,21 @@ static int hsk_fused_wide_splits(int64_t n_rows, int64_t item_count, int64_t k) 
   return (int)s;
 }
 
+// columns of the threshold-seeding sample (hsk_eval_seed_thresholds): 0 = no seeding
+static int64_t hsk_fused_seed_cols(int64_t item_count, int64_t k) {
+  // (lfm2b shape, one box: no seeding 1.09, 2048 columns 1.11, 4096 columns 1.155 M users/s)
+  static const int seed_on = getenv("HSK_FUSED_SEED") ? atoi(getenv("HSK_FUSED_SEED")) : 4096;
+  if (seed_on <= 0 || item_count < 4 * (int64_t)seed_on || k > seed_on / 4) return 0;
+  return hsk_align_up(seed_on, GEMM_W_BN);
+}
+
 // candidate slabs + partial lists of one layout
-static int64_t hsk_fused_sel_bytes(int64_t n_rows, int64_t k, int64_t s, int64_t bm, int64_t cap) {
+static int64_t hsk_fused_sel_bytes(int64_t n_rows, int64_t k, int64_t s, int64_t bm, int64_t cap, int64_t seed_cols = 0) {
   const int64_t row_blocks = hsk_ceil_div(n_rows, bm);
-  return hsk_align_up(row_blocks * s * bm * cap * 8, 256) + hsk_align_up(s * n_rows * k * 8, 256) + 256;
+  if (bm == GEMM_W_BM && s > 1) k = std::max<int64_t>(k, HSK_SEL_KMAX);   // (partial lists of the 256 x 256 kernel: pw entries)
+  return hsk_align_up(row_blocks * s * bm * cap * 8, 256) + hsk_align_up(s * n_rows * k * 8, 256) +
+         hsk_align_up(row_blocks * bm * 4, 256) +          // slabs, partial lists, shared thresholds
+         (seed_cols ? hsk_align_up(n_rows * seed_cols * 4, 256) + hsk_align_up(n_rows * k * 8, 256) : 0) + 256;
 }
 
 extern "C" int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count, int64_t k) {
@@ -927,7 +979,7 @@ extern "C" int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count
   // (the larger of the two kernels' layouts: which one runs also depends on whether the pieces' scratch is there)
   const int64_t narrow = hsk_fused_sel_bytes(n_rows, k, hsk_fused_splits(n_rows, item_count, k), FG_BM, HSK_SEL_CAP);
   const int sw = hsk_fused_wide_splits(n_rows, item_count, k);
-  const int64_t wide = sw ? hsk_fused_sel_bytes(n_rows, k, sw, GEMM_W_BM, FGW_CAP) : 0;
+  const int64_t wide = sw ? hsk_fused_sel_bytes(n_rows, k, sw, GEMM_W_BM, FGW_CAP, hsk_fused_seed_cols(item_count, k)) : 0;
   return std::max(narrow, wide);
 }
 
@@ -969,8 +1021,17 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
       char* p = (char*)ws;
       unsigned long long* slab = (unsigned long long*)p;
       p += hsk_align_up(row_blocks * SW * GEMM_W_BM * FGW_CAP * 8, 256);
+      const int pw = SW > 1 ? HSK_SEL_KMAX : (int)k;   // entries per row of a partial list
       float* part_vals = (float*)p;
-      int32_t* part_idx = (int32_t*)(p + (int64_t)SW * n_rows * k * 4);
+      int32_t* part_idx = (int32_t*)(p + (int64_t)SW * n_rows * pw * 4);
+      p += hsk_align_up((int64_t)SW * n_rows * pw * 8, 256);
+      uint32_t* gthr = (uint32_t*)p;   // shared / seeded thresholds (ordered keys; 0 = below everything)
+      p += hsk_align_up(row_blocks * GEMM_W_BM * 4, 256);
+      const int64_t seed_cols = hsk_fused_seed_cols(item_count, k);
+      float* seed_scores = (float*)p;
+      float* seed_vals = (float*)(p + hsk_align_up(n_rows * seed_cols * 4, 256));
+      int32_t* seed_idx = (int32_t*)(seed_vals + n_rows * k);
+      HSK_HIP(hipMemsetAsync(gthr, 0, (size_t)row_blocks * GEMM_W_BM * 4, stream));
       const int Dp = (int)hsk_align_up(dim, FG_BK);
       const int a_rows = (int)(row_blocks * GEMM_W_BM), b_rows = (int)(n_tiles * GEMM_W_BN);
       __bf16* Apl = (__bf16*)((char*)ws + need);
@@ -978,6 +1039,12 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
       hsk_eval_split_planes16(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, Apl, stream);
       hsk_eval_split_planes16(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, Bpl, stream);
       HSK_LAUNCH_CHECK();
+      if (seed_cols) {
+        int src = hsk_eval_seed_thresholds(item_bias, user_bias, global_bias, (int)n_users, Dp, u_idx, (int)n_rows,
+                                           (long long)item_begin, (int)seed_cols, excl_indptr, excl_indices, (int)k, Apl, Bpl,
+                                           a_rows, b_rows, seed_scores, seed_vals, seed_idx, gthr, status, stream);
+        if (src) return src;
+      }
       static bool lds_set[64] = {};   // per device: the opt-in for > 64 KB of dynamic LDS is a per-device attribute
       int dev = 0;
       HSK_HIP(hipGetDevice(&dev));
@@ -993,7 +1060,8 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
   k_score_topk_wide<IB, EX><<<grid, 256, FGW_LDS_BYTES, stream>>>(                                                     \
       item_bias, user_bias, global_bias, (int)n_users, Dp, u_idx, (int)n_rows, (long long)item_begin, (int)item_count, \
       tiles_per_split, excl_indptr, excl_indices, (int)k, SW, slab, SW == 1 ? out_vals : part_vals,                    \
-      SW == 1 ? out_idx : part_idx, status, Apl, Bpl, a_rows, b_rows)
+      SW == 1 ? out_idx : part_idx, status, Apl, Bpl, a_rows, b_rows, gthr, dbg, pw)
+      static const int dbg = getenv("HSK_FUSED_DEBUG") ? atoi(getenv("HSK_FUSED_DEBUG")) : 0;   // timing experiments
       const bool extra = user_bias || global_bias;
       if (item_bias) { if (extra) HSK_TOPK_WIDE(true, true); else HSK_TOPK_WIDE(true, false); }
       else           { if (extra) HSK_TOPK_WIDE(false, true); else HSK_TOPK_WIDE(false, false); }
@@ -1001,9 +1069,9 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
       HSK_LAUNCH_CHECK();
       if (SW > 1) {
         int npad = 1;
-        while (npad < SW * (int)k) npad <<= 1;
+        while (npad < SW * pw) npad <<= 1;
         k_fused_merge<<<(unsigned)n_rows, 256, 0, stream>>>(part_vals, part_idx, SW, (int)n_rows, (int)k, npad, out_vals,
-                                                            out_idx);
+                                                            out_idx, pw);
         HSK_LAUNCH_CHECK();
       }
       return HSK_OK;

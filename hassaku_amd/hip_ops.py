@@ -591,11 +591,10 @@ class BprMfFusedState:
 # evaluation
 # ------------------------------------------------------------------------------------------------
 FUSED_TOPK_MAX_K = 128     # hsk_mf_eval_topk_fused (HSK_SEL_KMAX)
-FUSED_TOPK_MIN_ITEMS = 36864   # (round 3, with the 256 x 256 score GEMM: materialised / fused M users/s at U = 16 384 --
-                               # 32 768 items 2.99 / 2.84, 40 960: 2.33 / 2.41)  below this many columns the warm-up of the in-GEMM selection (every row starts from
-                               # an empty list in every item split) costs more than writing the scores out: measured
-                               # 4.3 M users/s fused against 5.6 M materialised at 10 677 items, 0.62 M against 0.52 M
-                               # at 131 072
+FUSED_TOPK_MIN_ITEMS = 20480   # below this many columns the materialised path is the faster one.  Round 4, with the in-GEMM
+                               # selection on the 256 x 256 core, seeded and shared thresholds (csrc/hsk_eval_fused.hip:
+                               # k_score_topk_wide): materialised / fused M users/s at U = 16 384 -- 16 384 items 6.85 / 6.15,
+                               # 24 576: 3.88 / 4.38, 32 768: 2.98 / 3.57 (round 3's 128 x 128 selection crossed at 36 864)
 _fused_ws = {}             # device -> scratch of the fused selection, grown on demand
 _planes_ws = {}            # device -> scratch of the materialised path's bf16 pieces, grown on demand
 
