@@ -213,9 +213,11 @@ def _cfg5_share_worker(rank, world, port, out_dir):
         tu.step(uu, gU, s, orc)
         ti.step(it_sorted[first], gI, s, orc)
         tb.step(it_sorted[first], gIb[:, None], s, orc)
-        # (no next_start: a batch named ahead has its user rows replayed ahead of time behind this step -- the host
-        # model above reads a row's state as of step 0 when it first meets it; test_dist.py covers the ahead path)
-        sh.step_sampled(order, start)
+        # every step names its successor: the next batch is sampled, routed and item-sorted on the side stream under this
+        # step (the natively issued step's prefetch, as bench.py and the Trainer drive it).  The tables are not touched by
+        # that preparation (HSK_SHARD_AHEAD, the ahead-of-time replay of the next batch's rows, is off by default), so the
+        # host model above -- which reads a row's state as of step 0 when it first meets it -- stays exact.
+        sh.step_sampled(order, start, next_start=start + G if s < S else None)
         got = sh.last_loss()
         assert abs(got - loss) <= 2e-5 * abs(loss), (s, got, loss)
     sh.flush()

@@ -34,6 +34,23 @@ for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
             row = summary.setdefault(k, {})
             row[counter + '_KB_mean'] = tot / n
             row['dispatches'] = n
+# any further counters of an extra pass (tools/profile.sh PMC_EXTRA=...): per-dispatch means under their own names
+for path in glob.glob(os.path.join(src, 'pmc_extra', '**', '*counter_collection.csv'), recursive=True):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        k = short(r['Kernel_Name'])
+        if not k.startswith('k_'):
+            continue
+        a = acc.setdefault((k, r['Counter_Name']), [0.0, 0])
+        a[0] += float(r['Counter_Value'])
+        a[1] += 1
+    for (k, c), (tot, n) in acc.items():
+        summary.setdefault(k, {})[c + '_mean'] = tot / n
+for k, row in summary.items():
+    if 'SQ_VALU_MFMA_BUSY_CYCLES_mean' in row and row.get('SQ_BUSY_CYCLES_mean'):
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD-ish unit, SQ_BUSY_CYCLES per SQ (MI355X guide: quote the ratio,
+        # not an absolute): the share of the kernel's busy time in which a matrix pipe was busy
+        row['mfma_busy_over_sq_busy'] = row['SQ_VALU_MFMA_BUSY_CYCLES_mean'] / row['SQ_BUSY_CYCLES_mean']
 json.dump(summary, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
 
 for path in glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True):
