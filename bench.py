@@ -56,7 +56,7 @@ L2_GATHER_GBS = 17800.0      # same table: rows shared by every workgroup of an 
 HBM_GATHER_GBS = 5750.0      # same guide: random 2.3 KB rows of a table far beyond the Infinity Cache, 5.7-5.8 TB/s
 MFMA_FP32_TFLOPS = 157.0     # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32; no xf32 on gfx950)
 MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-PROFILE_DIR = {'ml10m': 'r3_ml10m', 'hbm': 'r3_hbm', 'ml1m': 'r2b_ml1m', 'ml100k': 'r2c_ml100k'}  # committed rocprofv3 summaries (PMC passes)
+PROFILE_DIR = {'ml10m': 'r4_ml10m', 'hbm': 'r4_hbm', 'ml1m': 'r4_ml1m', 'ml100k': 'r4_ml100k'}  # committed rocprofv3 summaries (PMC passes)
 LR, WD = 3e-4, 4e-5          # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
@@ -745,6 +745,32 @@ def run_sharded_1rank(workload, device):
             'eval_lfm2b_item_sharded_users_per_s': (x.get('eval') or {}).get('lfm2b', {}).get('users_per_s')}
 
 
+XGMI_LINK_GBS_PER_DIRECTION = 76.5   # guide: 7 links x ~153 GB/s per GPU, bidirectional -> per link and direction
+
+
+def predicted_scaling(sharded_us, item_us_guess, B, N, D):
+    """PREDICTION, not a measurement (no multi-GPU node has run this code): the weak-scaling step from the measured
+    one-rank sharded step and the guide's link rate.  The mesh is point to point: a rank sends its C user rows to each of
+    its W - 1 peers over that peer's own link, so a row exchange takes 4 D C / link rate whatever W is (C = user slots per
+    owner ~ B + 6 sigma + 8).  As built, the all_gather is exposed in full, the reduce_scatter hides under the item pass as
+    far as that lasts, the scalar reductions cost their latency.  `pipelined`: the design of MEASUREMENTS.md section 6
+    (step t+1's rows gathered under step t on a second communicator, the ~B/W rows both batches share patched after the
+    owners' update) -- not built."""
+    import math
+    out = {'note': 'PREDICTED from the measured 1-rank sharded step + %.1f GB/s per xGMI link and direction; weak scaling, '
+                   'B = %d per rank; nothing here was measured on more than one GPU' % (XGMI_LINK_GBS_PER_DIRECTION, B),
+           'one_rank_sharded_us': sharded_us, 'item_pass_us_assumed': item_us_guess, 'small_all_reduce_us_assumed': 15.0}
+    for W in (2, 4, 8):
+        G = W * B
+        C = G / W + 6.0 * math.sqrt(G / W * (1.0 - 1.0 / W)) + 8
+        t_x = 4.0 * D * C / (XGMI_LINK_GBS_PER_DIRECTION * 1e3)        # us per row exchange
+        as_built = sharded_us + t_x + max(0.0, t_x - item_us_guess) + 2 * 15.0
+        piped = sharded_us - 27.0 + max(0.0, t_x - item_us_guess) + 0.1 * t_x + 2 * 15.0   # catch-up + pack + gather off the path
+        out[f'W{W}'] = {'row_exchange_us': t_x, 'step_us_as_built': as_built, 'triplets_per_s_as_built': G * N / as_built * 1e6,
+                        'step_us_pipelined_design': piped, 'triplets_per_s_pipelined_design': G * N / piped * 1e6}
+    return out
+
+
 def guarded(fn, *a):
     """An extra leg must not cost the line its headline: a failure is recorded, not raised."""
     try:
@@ -894,6 +920,9 @@ def main():
             out['eval'] = {s: run_eval(s, device) for s in ('ml10m', 'lfm2b')}
             out['workloads']['cfg5_shard'] = children['cfg5_shard']
             out['sharded_1rank'] = children['sharded_1rank']
+            if 'ms_per_step' in children['sharded_1rank']:
+                out['predicted_scaling'] = predicted_scaling(children['sharded_1rank']['ms_per_step'] * 1e3, 90.0, r['B'],
+                                                             r['N'], r['D'])
             out['ieee_build'] = children['ieee_build']
             # the driver's protocol to the letter: exactly --warmup steps, no sweep in front of the fence
             x = guarded(run_training, args.workload, device, args.steps, args.warmup, None, not args.no_prefetch, 'auto',

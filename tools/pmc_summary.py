@@ -6,6 +6,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -14,6 +15,9 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
+    m = re.match(r'_Z(\d+)', name)       # names the profiler could not demangle (a __bf16 parameter): take the identifier
+    if m:
+        return name[m.end():m.end() + int(m.group(1))]
     return name.split('(')[0].replace('void ', '').strip()
 
 
@@ -50,7 +54,11 @@ for k, row in summary.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES_mean' in row and row.get('SQ_BUSY_CYCLES_mean'):
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD-ish unit, SQ_BUSY_CYCLES per SQ (MI355X guide: quote the ratio,
         # not an absolute): the share of the kernel's busy time in which a matrix pipe was busy
-        row['mfma_busy_over_sq_busy'] = row['SQ_VALU_MFMA_BUSY_CYCLES_mean'] / row['SQ_BUSY_CYCLES_mean']
+        if row['SQ_VALU_MFMA_BUSY_CYCLES_mean'] % float(1 << 32) == 0.0 and row['SQ_VALU_MFMA_BUSY_CYCLES_mean'] > 0:
+            row['mfma_busy_over_sq_busy'] = None      # the counter read a whole multiple of 2^32: it wrapped or saturated
+            row['note'] = 'SQ_VALU_MFMA_BUSY_CYCLES saturated over this dispatch; no ratio quoted'
+        else:
+            row['mfma_busy_over_sq_busy'] = row['SQ_VALU_MFMA_BUSY_CYCLES_mean'] / row['SQ_BUSY_CYCLES_mean']
 json.dump(summary, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
 
 for path in glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True):
