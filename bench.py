@@ -753,7 +753,7 @@ def predicted_scaling(sharded_us, item_us_guess, B, N, D):
     one-rank sharded step and the guide's link rate.  The mesh is point to point: a rank sends its C user rows to each of
     its W - 1 peers over that peer's own link, so a row exchange takes 4 D C / link rate whatever W is (C = user slots per
     owner ~ B + 6 sigma + 8).  As built, the all_gather is exposed in full, the reduce_scatter hides under the item pass as
-    far as that lasts, the scalar reductions cost their latency.  `pipelined`: the design of MEASUREMENTS.md section 6
+    far as that lasts, the scalar reductions cost their latency.  `pipelined`: the design of MEASUREMENTS.md R4.6
     (step t+1's rows gathered under step t on a second communicator, the ~B/W rows both batches share patched after the
     owners' update) -- not built."""
     import math
