@@ -568,6 +568,18 @@ def eval_problem(shape, device):
     return user_emb, item_emb, item_bias, _EvalData(U, I, npos, device)
 
 
+def eval_arithmetic(tf, world):
+    form = os.environ.get('HSK_EVAL_X3', '2')
+    if form == '0':
+        return {'arithmetic': 'exact-fp32 MFMA (HSK_EVAL_X3=0)'}
+    if form == '1':
+        return {'arithmetic': 'fp32-accurate scores from three bf16 pieces per operand, six bf16 MFMAs per block (HSK_EVAL_X3=1)',
+                'frac_of_bf16_six_product_peak_417': tf / (MFMA_BF16_TFLOPS / 6.0 * world)}
+    return {'arithmetic': 'fp32-accurate scores from two scaled fp16 pieces per operand, three fp16 MFMAs per block '
+                          '(default; HSK_EVAL_X3=1: three bf16 pieces / six MFMAs, 0: exact-fp32 MFMA)',
+            'frac_of_f16_three_product_peak_833': tf / (MFMA_BF16_TFLOPS / 3.0 * world)}
+
+
 def run_eval(shape, device, comm=None, chunk=None, repeat=3):
     """Full-catalogue evaluation (scores U x I^T, exclusion mask, top-100, precision/recall/ndcg at 100/50/10/5).
     comm None: one GPU.  Otherwise ITEM-SHARDED over the ranks on physically sliced tables (dist.evaluate_item_sharded)."""
@@ -622,11 +634,10 @@ def run_eval(shape, device, comm=None, chunk=None, repeat=3):
             'n_gpus': world, 'sharding': 'items (range-sharded tables, candidate all_to_all)' if comm is not None else 'none',
             'users_per_s': U / dt, 'seconds_per_full_eval': dt, 'tflops_fp32': tf,
             'frac_of_fp32_mfma_peak_157': tf / (MFMA_FP32_TFLOPS * world),
-            # the score GEMMs run on the bf16 matrix cores: every fp32 operand in three bf16 pieces, six bf16 MFMAs per
-            # product block (fp32-GEMM accuracy; csrc/hsk_eval.hip k_score_gemm_x3) -- 2500 / 6 TFLOP/s fp32-equivalent
-            'arithmetic': 'fp32-accurate scores from three bf16 pieces per operand, six bf16 MFMAs per block (HSK_EVAL_X3=0: exact-fp32 MFMA)'
-                          if os.environ.get('HSK_EVAL_X3', '1') != '0' else 'exact-fp32 MFMA',
-            'frac_of_bf16_six_product_peak_417': tf / (MFMA_BF16_TFLOPS / 6.0 * world),
+            # the score GEMMs run on the 16-bit matrix cores at fp32-GEMM accuracy: form 2 (default) two fp16 pieces per
+            # operand, three MFMAs per product block (csrc/hsk_gemm_wide_h2.h) -- 2500 / 3 TFLOP/s fp32-equivalent; form 1
+            # three bf16 pieces, six MFMAs (2500 / 6); form 0 the exact-fp32 MFMA (157)
+            **eval_arithmetic(tf, world),
             'ndcg@10_check': check['ndcg@10']}
 
 

@@ -4,8 +4,10 @@
 // Reference semantics restated: eval/eval.py:237-253 (scores, -inf mask), eval/eval.py:54-99
 // (topk(100), k in {100,50,10,5}), eval/metrics.py:4-105 (precision / recall / ndcg).
 #include "hsk_common.h"
-#include "hsk_gemm_wide.h"
+#include "hsk_gemm_wide_h2.h"
 #include <stdlib.h>
+
+#include <algorithm>
 
 #include <type_traits>
 
@@ -170,15 +172,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-// Which arithmetic the score GEMMs use (k_score_gemm* here, k_score_topk<.., X3> in hsk_eval_fused.hip): 1 (default) the
-// three-piece bf16 form, 0 the exact-fp32 MFMA form.  HSK_EVAL_X3 in the environment sets the initial value,
-// hsk_eval_set_arith changes it (parity tests compare the two forms).
+// Which arithmetic the score GEMMs use (k_score_gemm* here, k_score_topk* in hsk_eval_fused.hip): 2 (default) two fp16
+// pieces per operand / three products on the 256 x 256 kernels wherever the call brings the pieces' scratch and 16-byte
+// aligned rows (everything else runs form 1); 1 three bf16 pieces / six products; 0 the exact-fp32 MFMA form.
+// HSK_EVAL_X3 in the environment sets the initial value, hsk_eval_set_arith changes it (parity tests compare the forms).
 static int g_eval_x3 = -1;
 int hsk_eval_x3() {   // also called from hsk_eval_fused.hip
-  if (g_eval_x3 < 0) g_eval_x3 = getenv("HSK_EVAL_X3") ? (atoi(getenv("HSK_EVAL_X3")) != 0) : 1;
+  if (g_eval_x3 < 0) {
+    const int v = getenv("HSK_EVAL_X3") ? atoi(getenv("HSK_EVAL_X3")) : 2;
+    g_eval_x3 = v < 0 ? 0 : (v > 2 ? 2 : v);
+  }
   return g_eval_x3;
 }
-extern "C" void hsk_eval_set_arith(int three_piece_bf16) { g_eval_x3 = three_piece_bf16 ? 1 : 0; }
+extern "C" void hsk_eval_set_arith(int form) { g_eval_x3 = form < 0 ? 0 : (form > 2 ? 2 : form); }
 
 // ---------------------------------------------------------------------------------------------
 // The same scores from bf16 matrix cores.  Every fp32 operand is cut into three bf16 pieces while its tile is staged into
@@ -254,6 +260,78 @@ void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0,
 void hsk_eval_split_planes16(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
                              int n_pad, int D, void* planes, hipStream_t stream) {
   hsk_eval_split_planes_k(src, idx, row0, n_src_rows, n_valid, n_pad, D, planes, stream, 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Form 2: two fp16 pieces per operand (hsk_gemm_wide_h2.h).  The pre-pass first takes the largest finite |x| of the rows
+// it is about to cut -- those and no others: an item shard's table may be nothing but the shard (include/hassaku_hip.h).
+// A power-of-two scale changes no piece that stays a normal fp16, so shards of one catalogue (different maxima) agree
+// except in elements below 2^-17 of a maximum -- then writes hi / lo at the scale that puts that maximum in [2^14, 2^15),
+// laid out [Dp / 16 k-tiles][2 pieces][n_pad rows][16]: one (k-tile, piece) image of a 256-row block is 8 KB of
+// consecutive bytes.  The GEMM undoes both scales with one exact multiplication.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 hsk_f16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_absmax_rows(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                     long long row0, long long n_src_rows, long long n_rows, int D,
+                                                     uint32_t* __restrict__ out) {
+  const int per_row = D / 4;
+  const long long total = n_rows * per_row;
+  float m = 0.f;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long r = t / per_row;
+    const int k = (int)(t - r * per_row) * 4;
+    long long sr = idx ? idx[r] : row0 + r;
+    if (sr < 0 || sr >= n_src_rows) sr = idx ? 0 : row0;   // (a bad index is reported by the scoring kernel)
+    const float4 x = *reinterpret_cast<const float4*>(src + sr * (long long)D + k);
+    const float v[4] = {fabsf(x.x), fabsf(x.y), fabsf(x.z), fabsf(x.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (v[e] > m && v[e] < INFINITY) m = v[e];   // (NaN and inf do not take part)
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+__global__ __launch_bounds__(256) void k_split_planes_h2(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                         long long row0, long long n_src_rows, int n_valid, int n_pad, int D,
+                                                         int Dp, const uint32_t* __restrict__ amax,
+                                                         _Float16* __restrict__ planes) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = Dp / 4;
+  const long long r = t / per_row;
+  const int k = (int)(t - r * per_row) * 4;
+  if (r >= n_pad) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < n_valid && k < D) {
+    long long sr = idx ? idx[r] : row0 + r;
+    if (sr < 0 || sr >= n_src_rows) sr = 0;   // (a bad index is reported by the scoring kernel)
+    const float4 x = *reinterpret_cast<const float4*>(src + sr * (long long)D + k);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  }
+  const int e = hsk_h2_scale_exp(__uint_as_float(amax[0]));
+  hsk_f16x4 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    _Float16 a, b;
+    hsk_split_h2(v[q], e, a, b);
+    hi[q] = a; lo[q] = b;
+  }
+  _Float16* dst = planes + ((long long)(k / 16) * 2 * n_pad + r) * 16 + (k % 16);
+  *reinterpret_cast<hsk_f16x4*>(dst) = hi;
+  *reinterpret_cast<hsk_f16x4*>(dst + (long long)n_pad * 16) = lo;
+}
+
+// (also used by hsk_eval_fused.hip)  planes: 4 * n_pad * Dp bytes; amax: one zeroed word the call keeps for the GEMM to read
+void hsk_eval_split_planes_h2(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
+                              int n_pad, int D, uint32_t* amax, void* planes, hipStream_t stream) {
+  const int Dp = (int)hsk_align_up(D, GEMM_BK);
+  const long long work = (long long)n_valid * (D / 4);
+  const unsigned nb = (unsigned)std::min<long long>(2048, std::max<long long>(1, hsk_ceil_div(work, 256 * 4)));
+  k_absmax_rows<<<nb, 256, 0, stream>>>(src, idx, row0, n_src_rows, n_valid, D, amax);
+  const unsigned nblk = (unsigned)hsk_ceil_div((long long)n_pad * (Dp / 4), 256);
+  k_split_planes_h2<<<nblk, 256, 0, stream>>>(src, idx, row0, n_src_rows, n_valid, n_pad, D, Dp, amax, (_Float16*)planes);
 }
 
 typedef unsigned hsk_vu32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 structs ends up in scratch)
@@ -466,48 +544,23 @@ __global__ __launch_bounds__(256, 2) void k_score_gemm_x3(const float* __restric
 // Every output element sees the same sequence of MFMAs as in k_score_gemm_x3: the scores are bit-identical.
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256, 1) void k_score_gemm_x3_wide(const float* __restrict__ Ib, const float* __restrict__ Ub,
-                                                               const float* __restrict__ gb, int n_users, int Dp,
-                                                               const int64_t* __restrict__ u_idx, int n_rows,
-                                                               long long item_begin, int item_count,
-                                                               float* __restrict__ C, int32_t* status,
-                                                               const __bf16* __restrict__ Apl,
-                                                               const __bf16* __restrict__ Bpl, int a_rows, int b_rows) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 wlds[];
+// Epilogue of the 256 x 256 score GEMMs, through LDS.  One workgroup per CU: nothing covers this phase, so its length
+// counts in full -- and as dword-per-lane stores (256 per wave, every 128-byte piece split over two cache lines when the
+// row stride is not a multiple of 32 floats: item_count = 10 677) it took about a quarter of the kernel at the ml10m
+// shape.  Per band of 32 rows the four waves put their accumulators into LDS -- scaled by cs (form 2; exact), biases added
+// in the reference's order (+= u_bias, += i_bias, += global_bias), each row shifted by its own misalignment
+// (row * item_count + n0) mod 4 so that 16-byte pieces of LDS are 16-byte pieces of global memory -- and every wave then
+// writes 16 whole rows of the band's 256 columns with one ds_read_b128 + one global_store_dwordx4 per lane and row; the
+// ragged ends go out as dwords.  st: 2 x 32 rows of 264 floats = 67.6 KB of the (dead) operand stages.
+template <bool SCALE>
+__device__ __forceinline__ void hsk_wide_store_scores(const hsk_w_f32x16 (&acc)[4][4], float* st, float cs,
+                                                      const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                      const float* __restrict__ gb, int n_users,
+                                                      const int64_t* __restrict__ u_idx, int n_rows, long long item_begin,
+                                                      int item_count, float* __restrict__ C, int32_t* status, int m0, int n0,
+                                                      int lane, int wm, int wn, int r32, int h) {
   constexpr int TM = 4, TN = 4, WM = 128, WN = 128;
-  __bf16* As = wlds;
-  __bf16* Bs = wlds + 2 * GEMM_W_A_STAGE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GEMM_W_BM, n0 = blockIdx.x * GEMM_W_BN;
-  const int r32 = lane & 31, h = lane >> 5;
-  hsk_w_f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  hsk_wide_stage stg;
-  hsk_wide_init(stg, tid);
-  const int NT = Dp / GEMM_W_BK;
-  const __bf16* a0 = Apl + (long long)m0 * 48;
-  const __bf16* b0 = Bpl + (long long)n0 * 48;
-  const long long a_step = (long long)a_rows * 48, b_step = (long long)b_rows * 48;
-  hsk_wide_load(stg, a0, b0, tid);                     // k-tile 0 -> LDS stage 0
-  hsk_wide_store(stg, As, Bs);
-  hsk_wide_load(stg, a0 + (NT > 1 ? a_step : 0), b0 + (NT > 1 ? b_step : 0), tid);   // k-tile 1 -> registers
-  __syncthreads();
-  hsk_wide_kloop(acc, stg, As, Bs, a0, b0, a_step, b_step, NT, tid, wm, wn, r32, h);
-  // Epilogue through LDS.  One workgroup per CU: nothing covers this phase, so its length counts in full -- and as
-  // dword-per-lane stores (256 per wave, every 128-byte piece split over two cache lines when the row stride is not a
-  // multiple of 32 floats: item_count = 10 677) it took about a quarter of the kernel at the ml10m shape.  Per band of
-  // 32 rows the four waves put their accumulators into LDS -- biases added in the reference's order (+= u_bias, +=
-  // i_bias, += global_bias), each row shifted by its own misalignment (row * item_count + n0) mod 4 so that 16-byte
-  // pieces of LDS are 16-byte pieces of global memory -- and every wave then writes 16 whole rows of the band's 256
-  // columns with one ds_read_b128 + one global_store_dwordx4 per lane and row; the ragged ends go out as dwords.
   constexpr int LDR = 256 + 8;                       // floats per staged row (shift <= 3, 16-byte chunks conflict-free)
-  float* st = reinterpret_cast<float*>(wlds);        // 2 x 32 rows of LDR floats = 67.6 KB (the operand stages are dead)
   const float gbv = gb ? gb[0] : 0.f;
   const int ncols = min(256, item_count - n0);       // valid columns of this block
   const int ic3 = item_count & 3;
@@ -537,7 +590,7 @@ __global__ __launch_bounds__(256, 1) void k_score_gemm_x3_wide(const float* __re
       float* dst = st + (wm * 32 + rloc) * LDR + wn * WN + r32 + shift;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float o = acc[i][j][q];
+        float o = SCALE ? acc[i][j][q] * cs : acc[i][j][q];
         if (Ub) o += ub;
         if (Ib) o += ibv[j];
         if (gb) o += gbv;
@@ -566,6 +619,77 @@ __global__ __launch_bounds__(256, 1) void k_score_gemm_x3_wide(const float* __re
       if (lane < shift && 256 + lane < hi) gdst[256 + lane] = src[256 + lane];   // the chunk past lane 63
     }
   }
+}
+
+__global__ __launch_bounds__(256, 1) void k_score_gemm_x3_wide(const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                               const float* __restrict__ gb, int n_users, int Dp,
+                                                               const int64_t* __restrict__ u_idx, int n_rows,
+                                                               long long item_begin, int item_count,
+                                                               float* __restrict__ C, int32_t* status,
+                                                               const __bf16* __restrict__ Apl,
+                                                               const __bf16* __restrict__ Bpl, int a_rows, int b_rows) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 wlds[];
+  constexpr int TM = 4, TN = 4;
+  __bf16* As = wlds;
+  __bf16* Bs = wlds + 2 * GEMM_W_A_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GEMM_W_BM, n0 = blockIdx.x * GEMM_W_BN;
+  const int r32 = lane & 31, h = lane >> 5;
+  hsk_w_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  hsk_wide_stage stg;
+  hsk_wide_init(stg, tid);
+  const int NT = Dp / GEMM_W_BK;
+  const __bf16* a0 = Apl + (long long)m0 * 48;
+  const __bf16* b0 = Bpl + (long long)n0 * 48;
+  const long long a_step = (long long)a_rows * 48, b_step = (long long)b_rows * 48;
+  hsk_wide_load(stg, a0, b0, tid);                     // k-tile 0 -> LDS stage 0
+  hsk_wide_store(stg, As, Bs);
+  hsk_wide_load(stg, a0 + (NT > 1 ? a_step : 0), b0 + (NT > 1 ? b_step : 0), tid);   // k-tile 1 -> registers
+  __syncthreads();
+  hsk_wide_kloop(acc, stg, As, Bs, a0, b0, a_step, b_step, NT, tid, wm, wn, r32, h);
+  hsk_wide_store_scores<false>(acc, reinterpret_cast<float*>(wlds), 1.f, Ib, Ub, gb, n_users, u_idx, n_rows, item_begin, item_count,
+                               C, status, m0, n0, lane, wm, wn, r32, h);
+}
+
+// The same on two fp16 pieces per operand, three products (hsk_gemm_wide_h2.h; planes from hsk_eval_split_planes_h2).
+// amax[0] / amax[1]: the largest |x| the user / item pieces were scaled by.
+__global__ __launch_bounds__(256, 1) void k_score_gemm_h2_wide(const float* __restrict__ Ib, const float* __restrict__ Ub,
+                                                               const float* __restrict__ gb, int n_users, int Dp,
+                                                               const int64_t* __restrict__ u_idx, int n_rows,
+                                                               long long item_begin, int item_count,
+                                                               float* __restrict__ C, int32_t* status,
+                                                               const _Float16* __restrict__ Apl,
+                                                               const _Float16* __restrict__ Bpl, int a_rows, int b_rows,
+                                                               const uint32_t* __restrict__ amax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GEMM_W_BM, n0 = blockIdx.x * GEMM_W_BN;
+  const int r32 = lane & 31, h = lane >> 5;
+  hsk_w_f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  const float cs = ldexpf(1.f, -(hsk_h2_scale_exp(__uint_as_float(amax[0])) + hsk_h2_scale_exp(__uint_as_float(amax[1]))));
+  hsk_h2_stage stg;
+  const int NT = Dp / GEMM_H_BK;
+  hsk_h2_load(stg, Apl, Bpl, a_rows, b_rows, m0, n0, 0, tid);                  // k-step 0 -> LDS stage 0
+  hsk_h2_store(stg, hlds, tid);
+  hsk_h2_load(stg, Apl, Bpl, a_rows, b_rows, m0, n0, NT > 1 ? 1 : 0, tid);     // k-step 1 -> registers
+  __syncthreads();
+  hsk_h2_kloop(acc, stg, hlds, Apl, Bpl, a_rows, b_rows, m0, n0, NT, tid, wm, wn, r32, h);
+  hsk_wide_store_scores<true>(acc, reinterpret_cast<float*>(hlds), cs, Ib, Ub, gb, n_users, u_idx, n_rows, item_begin, item_count,
+                              C, status, m0, n0, lane, wm, wn, r32, h);
 }
 
 // excluded (user, item) pairs -> -inf.  One wave per eval row, lanes stride over the user's CSR row.
@@ -1114,6 +1238,19 @@ static int hsk_launch_topk_i32(const float* X, int64_t rows, int64_t cols, int64
   return HSK_OK;
 }
 
+// the opt-in for > 64 KB of dynamic LDS is a per-device attribute of each kernel
+static int hsk_eval_set_wide_lds() {
+  static bool lds_set[64] = {};
+  int dev = 0;
+  HSK_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !lds_set[dev]) {
+    HSK_HIP(hipFuncSetAttribute((const void*)k_score_gemm_x3_wide, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_W_LDS_BYTES));
+    HSK_HIP(hipFuncSetAttribute((const void*)k_score_gemm_h2_wide, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_H_LDS_BYTES));
+    lds_set[dev] = true;
+  }
+  return HSK_OK;
+}
+
 extern "C" int64_t hsk_mf_eval_planes_bytes(int64_t n_rows, int64_t item_count, int64_t dim) {
   if (n_rows <= 0 || item_count <= 0 || dim <= 0) return 0;
   const int64_t Dp = hsk_align_up(dim, GEMM_BK);
@@ -1161,9 +1298,27 @@ extern "C" int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_
   static const int planes_on = getenv("HSK_EVAL_PLANES") ? atoi(getenv("HSK_EVAL_PLANES")) : 1;
   if (x3 && vec4 && planes_on && planes_ws && ((uintptr_t)planes_ws & 255) == 0 &&
       planes_bytes >= hsk_mf_eval_planes_bytes(n_rows, item_count, dim)) {
-    // the operands' bf16 pieces, made once for the call
+    // the operands' pieces, made once for the call
     const int64_t Dp = hsk_align_up(dim, GEMM_BK);
     const int a_rows = (int)hsk_align_up(n_rows, GEMM_W_BM), b_rows = (int)hsk_align_up(item_count, GEMM_W_BN);
+    if (x3 == 2) {
+      // form 2: fp16 pairs (4 of the region's 6 bytes per element; the two scale words sit in its last 256 bytes),
+      // the 256 x 256 kernel whatever the shape
+      _Float16* Ah = (_Float16*)planes_ws;
+      _Float16* Bh = (_Float16*)((char*)planes_ws + hsk_align_up(6 * (int64_t)a_rows * Dp, 256));
+      uint32_t* amax = (uint32_t*)((char*)planes_ws + hsk_mf_eval_planes_bytes(n_rows, item_count, dim) - 256);
+      HSK_HIP(hipMemsetAsync(amax, 0, 8, stream));
+      hsk_eval_split_planes_h2(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, amax, Ah, stream);
+      hsk_eval_split_planes_h2(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, amax + 1, Bh, stream);
+      HSK_LAUNCH_CHECK();
+      int rc = hsk_eval_set_wide_lds();
+      if (rc) return rc;
+      dim3 wgrid((unsigned)hsk_ceil_div(item_count, GEMM_W_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_W_BM));
+      k_score_gemm_h2_wide<<<wgrid, 256, GEMM_H_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, (int)n_users, (int)Dp,
+                                                                     u_idx, (int)n_rows, (long long)item_begin,
+                                                                     (int)item_count, scores_ws, status, Ah, Bh, a_rows, b_rows,
+                                                                     amax);
+    } else {
     __bf16* Apl = (__bf16*)planes_ws;
     __bf16* Bpl = (__bf16*)((char*)planes_ws + hsk_align_up(6 * (int64_t)a_rows * Dp, 256));
     // 256 x 256 block tiles (one wave per SIMD) once there are enough of them to fill the chip a few times over;
@@ -1176,14 +1331,8 @@ extern "C" int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_
                             wide ? 16 : GEMM_BK);
     HSK_LAUNCH_CHECK();
     if (wide) {
-      static bool lds_set[64] = {};   // per device: the opt-in for > 64 KB of dynamic LDS is a per-device attribute
-      int dev = 0;
-      HSK_HIP(hipGetDevice(&dev));
-      if (dev >= 0 && dev < 64 && !lds_set[dev]) {
-        HSK_HIP(hipFuncSetAttribute((const void*)k_score_gemm_x3_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    GEMM_W_LDS_BYTES));
-        lds_set[dev] = true;
-      }
+      int rc = hsk_eval_set_wide_lds();
+      if (rc) return rc;
       dim3 wgrid((unsigned)hsk_ceil_div(item_count, GEMM_W_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_W_BM));
       k_score_gemm_x3_wide<<<wgrid, 256, GEMM_W_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, (int)n_users,
                                                                      (int)Dp, u_idx, (int)n_rows, (long long)item_begin,
@@ -1194,6 +1343,7 @@ extern "C" int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_
                                                            (int)n_users, (int)dim, u_idx, (int)n_rows,
                                                            (long long)item_begin, (int)item_count, scores_ws, status, Apl,
                                                            Bpl, a_rows, b_rows);
+    }
     }
   } else if (x3) {
     if (vec4) HSK_SCORE_GEMM(k_score_gemm_x3<true>); else HSK_SCORE_GEMM(k_score_gemm_x3<false>);
@@ -1227,20 +1377,20 @@ __global__ __launch_bounds__(256) void k_seed_keys(const float* __restrict__ val
 
 int hsk_eval_seed_thresholds(const float* item_bias, const float* user_bias, const float* global_bias, int n_users, int Dp,
                              const int64_t* u_idx, int n_rows, long long item_begin, int sample_count,
-                             const int64_t* excl_indptr, const int32_t* excl_indices, int k, const __bf16* Apl,
-                             const __bf16* Bpl, int a_rows, int b_rows, float* scores_ws, float* vals_ws, int32_t* idx_ws,
-                             uint32_t* gthr, int32_t* status, hipStream_t stream) {
-  static bool lds_set[64] = {};
-  int dev = 0;
-  HSK_HIP(hipGetDevice(&dev));
-  if (dev >= 0 && dev < 64 && !lds_set[dev]) {
-    HSK_HIP(hipFuncSetAttribute((const void*)k_score_gemm_x3_wide, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_W_LDS_BYTES));
-    lds_set[dev] = true;
-  }
+                             const int64_t* excl_indptr, const int32_t* excl_indices, int k, const void* Apl,
+                             const void* Bpl, int a_rows, int b_rows, const uint32_t* amax, float* scores_ws, float* vals_ws,
+                             int32_t* idx_ws, uint32_t* gthr, int32_t* status, hipStream_t stream) {
+  int rc0 = hsk_eval_set_wide_lds();
+  if (rc0) return rc0;
   dim3 wgrid((unsigned)hsk_ceil_div(sample_count, GEMM_W_BN), (unsigned)hsk_ceil_div(n_rows, GEMM_W_BM));
-  k_score_gemm_x3_wide<<<wgrid, 256, GEMM_W_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, n_users, Dp, u_idx, n_rows,
-                                                                 item_begin, sample_count, scores_ws, status, Apl, Bpl, a_rows,
-                                                                 b_rows);
+  if (amax)   // form 2: the pieces are fp16 pairs
+    k_score_gemm_h2_wide<<<wgrid, 256, GEMM_H_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, n_users, Dp, u_idx, n_rows,
+                                                                   item_begin, sample_count, scores_ws, status,
+                                                                   (const _Float16*)Apl, (const _Float16*)Bpl, a_rows, b_rows, amax);
+  else
+    k_score_gemm_x3_wide<<<wgrid, 256, GEMM_W_LDS_BYTES, stream>>>(item_bias, user_bias, global_bias, n_users, Dp, u_idx, n_rows,
+                                                                   item_begin, sample_count, scores_ws, status,
+                                                                   (const __bf16*)Apl, (const __bf16*)Bpl, a_rows, b_rows);
   HSK_LAUNCH_CHECK();
   if (excl_indptr) {
     k_mask_excluded<<<(unsigned)hsk_ceil_div(n_rows, 4), 256, 0, stream>>>(u_idx, n_rows, n_users, excl_indptr, excl_indices,

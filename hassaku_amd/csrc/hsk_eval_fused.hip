@@ -16,7 +16,7 @@
 // lists of a row.  Excluded (user, item) pairs become -inf exactly as in the reference (they can still appear in the
 // top k of a user with fewer than k admissible items, lowest item id first).
 #include "hsk_common.h"
-#include "hsk_gemm_wide.h"
+#include "hsk_gemm_wide_h2.h"
 #include <stdlib.h>
 
 #include <algorithm>
@@ -538,19 +538,23 @@ __global__ __launch_bounds__(256, 2) void k_score_topk(const float* __restrict__
 #define FGW_Q 1536             // queue entries per wave: drained when it holds > 512 (a band adds at most 16 sites x 64 lanes)
 #define FGW_STATE_BYTES (3 * 256 * 4 + 256 * 8 * 4)   // thr, cnt, ubias [256] + emask [256][8]
 #define FGW_LDS_BYTES (GEMM_W_LDS_BYTES + FGW_STATE_BYTES)
+#define FGW_H2_LDS_BYTES (GEMM_H_LDS_BYTES + FGW_STATE_BYTES)   // on the fp16-pair core (hsk_gemm_wide_h2.h)
 static_assert(FGW_LDS_BYTES <= 160 * 1024, "LDS of k_score_topk_wide");
-static_assert(4 * FGW_Q * 20 + 4 * 256 * 4 + 4 * HSK_SEL_KMAX * 8 <= GEMM_W_LDS_BYTES, "queues + select scratch fit the idle stages");
+static_assert(4 * FGW_Q * 20 + 4 * 256 * 4 + 4 * HSK_SEL_KMAX * 8 <= GEMM_H_LDS_BYTES && GEMM_H_LDS_BYTES <= GEMM_W_LDS_BYTES,
+              "queues + select scratch fit the idle stages");
 
 // HAS_IB: item bias present; EXTRA: a user and / or global bias as well (the additions follow the reference's order and
 // are left out, not replaced by + 0, where a bias is absent: -0 + 0 would change a sign bit the materialised path keeps)
-template <bool HAS_IB, bool EXTRA>
+// H2: the fp16-pair / three-product core (form 2 of hsk_eval_set_arith): Apl / Bpl are its planes, amax the two maxima the
+// planes were scaled by; every score is the accumulator times 2^-(e_a + e_b), exact
+template <bool HAS_IB, bool EXTRA, bool H2 = false>
 __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
     const float* __restrict__ Ib, const float* __restrict__ Ub, const float* __restrict__ gb, int n_users, int Dp,
     const int64_t* __restrict__ u_idx, int n_rows, long long item_begin, int item_count, int tiles_per_split,
     const int64_t* __restrict__ excl_indptr, const int32_t* __restrict__ excl_indices, int k, int n_splits,
     unsigned long long* __restrict__ cand_ws, float* __restrict__ part_vals, int32_t* __restrict__ part_idx,
-    int32_t* status, const __bf16* __restrict__ Apl, const __bf16* __restrict__ Bpl, int a_rows, int b_rows,
-    uint32_t* __restrict__ gthr, int dbg, int pw) {
+    int32_t* status, const void* __restrict__ Apl_, const void* __restrict__ Bpl_, int a_rows, int b_rows,
+    uint32_t* __restrict__ gthr, int dbg, int pw, const uint32_t* __restrict__ amax) {
   // pw: entries per row of this split's partial list: k (one split: the final, sorted list) or HSK_SEL_KMAX (several:
   // k_fused_merge sorts the union anyway, so a row that ends with <= pw survivors is handed over as it is -- no select)
   // gthr [n_rows] (zero-initialised keys): the best threshold any split has reached for the row.  A split's k-th best score
@@ -563,7 +567,14 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
   constexpr int BM = GEMM_W_BM, BN = GEMM_W_BN, TM = 4, TN = 4;
   __bf16* As = wlds;
   __bf16* Bs = wlds + 2 * GEMM_W_A_STAGE;
-  unsigned char* state = reinterpret_cast<unsigned char*>(wlds) + GEMM_W_LDS_BYTES;
+  const __bf16* __restrict__ Apl = reinterpret_cast<const __bf16*>(Apl_);
+  const __bf16* __restrict__ Bpl = reinterpret_cast<const __bf16*>(Bpl_);
+  const _Float16* __restrict__ Ah = reinterpret_cast<const _Float16*>(Apl_);
+  const _Float16* __restrict__ Bh = reinterpret_cast<const _Float16*>(Bpl_);
+  unsigned char* hlds = reinterpret_cast<unsigned char*>(wlds);
+  unsigned char* state = reinterpret_cast<unsigned char*>(wlds) + (H2 ? GEMM_H_LDS_BYTES : GEMM_W_LDS_BYTES);
+  float cs = 1.f;
+  if constexpr (H2) cs = ldexpf(1.f, -(hsk_h2_scale_exp(__uint_as_float(amax[0])) + hsk_h2_scale_exp(__uint_as_float(amax[1]))));
   float* thr = reinterpret_cast<float*>(state);               // [256] current k-th best score of the row
   int* cnt = reinterpret_cast<int*>(state + 1024);            // [256] candidates the row holds
   float* ubias = reinterpret_cast<float*>(state + 2048);      // [256]
@@ -691,12 +702,17 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
 
   hsk_w_f32x16 acc[TM][TN];
   hsk_wide_stage stg;
-  hsk_wide_init(stg, tid);
-  const int NT = Dp / GEMM_W_BK;
+  hsk_h2_stage hstg;
+  if constexpr (!H2) hsk_wide_init(stg, tid);
+  const int NT = H2 ? Dp / GEMM_H_BK : Dp / GEMM_W_BK;
   const long long a_step = (long long)a_rows * 48, b_step = (long long)b_rows * 48;
   const __bf16* a0 = Apl + (long long)m0 * 48;
-  // first tile of the split: k-tile 0 -> LDS stage 0, k-tile 1 -> registers
-  {
+  // first tile of the split: k-step 0 -> LDS stage 0, k-step 1 -> registers
+  if constexpr (H2) {
+    hsk_h2_load(hstg, Ah, Bh, a_rows, b_rows, m0, t_lo * BN, 0, tid);
+    hsk_h2_store(hstg, hlds, tid);
+    hsk_h2_load(hstg, Ah, Bh, a_rows, b_rows, m0, t_lo * BN, NT > 1 ? 1 : 0, tid);
+  } else {
     const __bf16* b0 = Bpl + (long long)t_lo * BN * 48;
     hsk_wide_load(stg, a0, b0, tid);
     hsk_wide_store(stg, As, Bs);
@@ -732,9 +748,14 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     __syncthreads();   // stage 0 of this tile is in place (stored behind the previous tile's compactions)
-    hsk_wide_kloop(acc, stg, As, Bs, a0, b0, a_step, b_step, NT, tid, wm, wn, r32, h);
     const bool more = tile + 1 < t_hi;
-    if (more) hsk_wide_load(stg, a0, b0 + (long long)BN * 48, tid);   // next tile's k-tile 0: in flight during the epilogue
+    if constexpr (H2) {
+      hsk_h2_kloop(acc, hstg, hlds, Ah, Bh, a_rows, b_rows, m0, n0, NT, tid, wm, wn, r32, h);
+      if (more) hsk_h2_load(hstg, Ah, Bh, a_rows, b_rows, m0, n0 + BN, 0, tid);   // next tile's k-step 0: in flight during the epilogue
+    } else {
+      hsk_wide_kloop(acc, stg, As, Bs, a0, b0, a_step, b_step, NT, tid, wm, wn, r32, h);
+      if (more) hsk_wide_load(stg, a0, b0 + (long long)BN * 48, tid);
+    }
 
     // ---- epilogue: filter -> per-wave queue -> dense drain, band by band ---------------------------------------
     float ibv[TN];
@@ -767,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
         hsk_f32x4 o;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          float x = acc[i][j][q];
+          float x = H2 ? acc[i][j][q] * cs : acc[i][j][q];
           if (EXTRA) {   // reference order: += u_bias, += i_bias, += global_bias
             if (Ub) x += ub_b[i * 32 + (q & 3) + 8 * (q >> 2)];
             if (HAS_IB) x += ibv[j];
@@ -830,9 +851,14 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
     }
     __syncthreads();   // queues and select scratch are dead: the stages may be refilled
     if (more) {
-      const __bf16* b1 = b0 + (long long)BN * 48;
-      hsk_wide_store(stg, As, Bs);
-      hsk_wide_load(stg, a0 + (NT > 1 ? a_step : 0), b1 + (NT > 1 ? b_step : 0), tid);
+      if constexpr (H2) {
+        hsk_h2_store(hstg, hlds, tid);
+        hsk_h2_load(hstg, Ah, Bh, a_rows, b_rows, m0, n0 + BN, NT > 1 ? 1 : 0, tid);
+      } else {
+        const __bf16* b1 = b0 + (long long)BN * 48;
+        hsk_wide_store(stg, As, Bs);
+        hsk_wide_load(stg, a0 + (NT > 1 ? a_step : 0), b1 + (NT > 1 ? b_step : 0), tid);
+      }
     }
   }
 
@@ -910,9 +936,12 @@ void hsk_eval_split_planes(const float* src, const int64_t* idx, long long row0,
                            int n_pad, int D, void* planes, hipStream_t stream);
 int hsk_eval_seed_thresholds(const float* item_bias, const float* user_bias, const float* global_bias, int n_users, int Dp,
                              const int64_t* u_idx, int n_rows, long long item_begin, int sample_count,
-                             const int64_t* excl_indptr, const int32_t* excl_indices, int k, const __bf16* Apl,
-                             const __bf16* Bpl, int a_rows, int b_rows, float* scores_ws, float* vals_ws, int32_t* idx_ws,
-                             uint32_t* gthr, int32_t* status, hipStream_t stream);   // hsk_eval.hip
+                             const int64_t* excl_indptr, const int32_t* excl_indices, int k, const void* Apl,
+                             const void* Bpl, int a_rows, int b_rows, const uint32_t* amax, float* scores_ws, float* vals_ws,
+                             int32_t* idx_ws, uint32_t* gthr, int32_t* status, hipStream_t stream);   // hsk_eval.hip
+// form 2: fp16 pairs [k-tile of 16][piece][row][16] at the scale of the rows' largest |x| (hsk_gemm_wide_h2.h)
+void hsk_eval_split_planes_h2(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
+                              int n_pad, int D, uint32_t* amax, void* planes, hipStream_t stream);
 // ... laid out [k-tile of 16][row][piece][16]: what the 256 x 256 core reads
 void hsk_eval_split_planes16(const float* src, const int64_t* idx, long long row0, long long n_src_rows, int n_valid,
                              int n_pad, int D, void* planes, hipStream_t stream);
@@ -943,8 +972,10 @@ static int hsk_fused_splits(int64_t n_rows, int64_t item_count, int64_t k) {
 // The 256 x 256 kernel: ONE workgroup per CU, so 256 of them are a full round.  Splits of the catalogue for it, or 0 when
 // the call is not for it (too few tiles per split: a split's first tiles are all warm-up -- every score passes until the
 // rows hold k candidates).  HSK_FUSED_WIDE: 0 never, 2 whenever the shape allows, 1 (default) by this rule.
-static int hsk_fused_wide_splits(int64_t n_rows, int64_t item_count, int64_t k) {
-  static const int wide_on = getenv("HSK_FUSED_WIDE") ? atoi(getenv("HSK_FUSED_WIDE")) : 1;
+// force: form 2 of the arithmetic -- the fp16-pair core only exists at 256 x 256, so every shape takes this kernel
+static int hsk_fused_wide_splits(int64_t n_rows, int64_t item_count, int64_t k, bool force = false) {
+  static const int wide_env = getenv("HSK_FUSED_WIDE") ? atoi(getenv("HSK_FUSED_WIDE")) : 1;
+  const int wide_on = force ? 2 : wide_env;
   if (!wide_on) return 0;
   const int64_t row_blocks = hsk_ceil_div(n_rows, GEMM_W_BM), n_tiles = hsk_ceil_div(item_count, GEMM_W_BN);
   static const int target_wgs = getenv("HSK_FUSED_WIDE_WGS") ? atoi(getenv("HSK_FUSED_WIDE_WGS")) : 256;
@@ -978,8 +1009,12 @@ extern "C" int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count
   if (n_rows <= 0 || item_count <= 0 || k <= 0 || k > HSK_SEL_KMAX) return -1;
   // (the larger of the two kernels' layouts: which one runs also depends on whether the pieces' scratch is there)
   const int64_t narrow = hsk_fused_sel_bytes(n_rows, k, hsk_fused_splits(n_rows, item_count, k), FG_BM, HSK_SEL_CAP);
-  const int sw = hsk_fused_wide_splits(n_rows, item_count, k);
-  const int64_t wide = sw ? hsk_fused_sel_bytes(n_rows, k, sw, GEMM_W_BM, FGW_CAP, hsk_fused_seed_cols(item_count, k)) : 0;
+  // (... and, since the arithmetic can be switched between sizing and running a call, on both rules for the 256 x 256 one)
+  int64_t wide = 0;
+  for (int force = 0; force < 2; ++force) {
+    const int sw = hsk_fused_wide_splits(n_rows, item_count, k, force != 0);
+    if (sw) wide = std::max(wide, hsk_fused_sel_bytes(n_rows, k, sw, GEMM_W_BM, FGW_CAP, hsk_fused_seed_cols(item_count, k)));
+  }
   return std::max(narrow, wide);
 }
 
@@ -1012,7 +1047,8 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
   {
     // the 256 x 256 / one-wave-per-SIMD kernel: needs the operands' pieces (k-tiles of 16) and enough tiles per split
     static const int planes_on_w = getenv("HSK_EVAL_PLANES") ? atoi(getenv("HSK_EVAL_PLANES")) : 1;
-    const int SW = hsk_fused_wide_splits(n_rows, item_count, k);
+    const bool h2 = hsk_eval_x3() == 2;
+    const int SW = hsk_fused_wide_splits(n_rows, item_count, k, h2);
     const bool vec4w = (dim % 4 == 0) && ((((uintptr_t)user_emb | (uintptr_t)item_emb) & 15) == 0);
     if (SW && hsk_eval_x3() && planes_on_w && planes_on_w != 3 && vec4w &&
         ws_bytes >= need + hsk_fused_plane_bytes(n_rows, item_count, dim)) {
@@ -1034,37 +1070,52 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
       HSK_HIP(hipMemsetAsync(gthr, 0, (size_t)row_blocks * GEMM_W_BM * 4, stream));
       const int Dp = (int)hsk_align_up(dim, FG_BK);
       const int a_rows = (int)(row_blocks * GEMM_W_BM), b_rows = (int)(n_tiles * GEMM_W_BN);
-      __bf16* Apl = (__bf16*)((char*)ws + need);
-      __bf16* Bpl = (__bf16*)((char*)Apl + hsk_align_up(3 * (int64_t)a_rows * Dp * 2, 256));
-      hsk_eval_split_planes16(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, Apl, stream);
-      hsk_eval_split_planes16(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, Bpl, stream);
+      void* Apl = (char*)ws + need;
+      void* Bpl = (char*)Apl + hsk_align_up(3 * (int64_t)a_rows * Dp * 2, 256);
+      // (form 2: fp16 pairs fill 4 of the regions' 6 bytes per element; the two scale words sit in the last 256 bytes)
+      uint32_t* amax = h2 ? (uint32_t*)((char*)Apl + hsk_fused_plane_bytes(n_rows, item_count, dim) - 256) : nullptr;
+      if (h2) {
+        HSK_HIP(hipMemsetAsync(amax, 0, 8, stream));
+        hsk_eval_split_planes_h2(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, amax, Apl, stream);
+        hsk_eval_split_planes_h2(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, amax + 1, Bpl,
+                                 stream);
+      } else {
+        hsk_eval_split_planes16(user_emb, u_idx, 0, n_users, (int)n_rows, a_rows, (int)dim, Apl, stream);
+        hsk_eval_split_planes16(item_emb, nullptr, item_begin, n_items, (int)item_count, b_rows, (int)dim, Bpl, stream);
+      }
       HSK_LAUNCH_CHECK();
       if (seed_cols) {
         int src = hsk_eval_seed_thresholds(item_bias, user_bias, global_bias, (int)n_users, Dp, u_idx, (int)n_rows,
                                            (long long)item_begin, (int)seed_cols, excl_indptr, excl_indices, (int)k, Apl, Bpl,
-                                           a_rows, b_rows, seed_scores, seed_vals, seed_idx, gthr, status, stream);
+                                           a_rows, b_rows, amax, seed_scores, seed_vals, seed_idx, gthr, status, stream);
         if (src) return src;
       }
       static bool lds_set[64] = {};   // per device: the opt-in for > 64 KB of dynamic LDS is a per-device attribute
       int dev = 0;
       HSK_HIP(hipGetDevice(&dev));
       if (dev >= 0 && dev < 64 && !lds_set[dev]) {
-        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
-        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
-        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
-        HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES));
+#define HSK_TOPK_WIDE_LDS(IB, EX)                                                                                                     \
+  HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<IB, EX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_LDS_BYTES)); \
+  HSK_HIP(hipFuncSetAttribute((const void*)k_score_topk_wide<IB, EX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FGW_H2_LDS_BYTES))
+        HSK_TOPK_WIDE_LDS(true, false);
+        HSK_TOPK_WIDE_LDS(true, true);
+        HSK_TOPK_WIDE_LDS(false, false);
+        HSK_TOPK_WIDE_LDS(false, true);
+#undef HSK_TOPK_WIDE_LDS
         lds_set[dev] = true;
       }
       const unsigned grid = (unsigned)(hsk_ceil_div(row_blocks, 8) * 8 * SW);
-#define HSK_TOPK_WIDE(IB, EX)                                                                                          \
-  k_score_topk_wide<IB, EX><<<grid, 256, FGW_LDS_BYTES, stream>>>(                                                     \
+#define HSK_TOPK_WIDE_K(IB, EX, H)                                                                                     \
+  k_score_topk_wide<IB, EX, H><<<grid, 256, H ? FGW_H2_LDS_BYTES : FGW_LDS_BYTES, stream>>>(                            \
       item_bias, user_bias, global_bias, (int)n_users, Dp, u_idx, (int)n_rows, (long long)item_begin, (int)item_count, \
       tiles_per_split, excl_indptr, excl_indices, (int)k, SW, slab, SW == 1 ? out_vals : part_vals,                    \
-      SW == 1 ? out_idx : part_idx, status, Apl, Bpl, a_rows, b_rows, gthr, dbg, pw)
+      SW == 1 ? out_idx : part_idx, status, Apl, Bpl, a_rows, b_rows, gthr, dbg, pw, amax)
+#define HSK_TOPK_WIDE(IB, EX) do { if (h2) HSK_TOPK_WIDE_K(IB, EX, true); else HSK_TOPK_WIDE_K(IB, EX, false); } while (0)
       static const int dbg = getenv("HSK_FUSED_DEBUG") ? atoi(getenv("HSK_FUSED_DEBUG")) : 0;   // timing experiments
       const bool extra = user_bias || global_bias;
       if (item_bias) { if (extra) HSK_TOPK_WIDE(true, true); else HSK_TOPK_WIDE(true, false); }
       else           { if (extra) HSK_TOPK_WIDE(false, true); else HSK_TOPK_WIDE(false, false); }
+#undef HSK_TOPK_WIDE_K
 #undef HSK_TOPK_WIDE
       HSK_LAUNCH_CHECK();
       if (SW > 1) {

@@ -599,10 +599,15 @@ _fused_ws = {}             # device -> scratch of the fused selection, grown on 
 _planes_ws = {}            # device -> scratch of the materialised path's bf16 pieces, grown on demand
 
 
-def set_eval_arith(three_piece_bf16: bool):
-    """Arithmetic of the score GEMMs (materialised and fused top-k): True (default) three bf16 pieces per fp32 operand,
-    False exact fp32 MFMA; see hsk_eval_set_arith in include/hassaku_hip.h."""
-    _lib.load().hsk_eval_set_arith(1 if three_piece_bf16 else 0)
+EVAL_ARITH_FP32, EVAL_ARITH_BF16X3, EVAL_ARITH_F16X2 = 0, 1, 2
+EVAL_ARITH_DEFAULT = EVAL_ARITH_F16X2
+
+
+def set_eval_arith(form=EVAL_ARITH_DEFAULT):
+    """Arithmetic of the score GEMMs (materialised and fused top-k): 2 (default) two fp16 pieces per fp32 operand and three
+    products on the 256 x 256 kernels (calls without the pieces' scratch or with rows that are not 16-byte aligned run
+    form 1), 1 three bf16 pieces and six products, 0 exact fp32 MFMA; see hsk_eval_set_arith in include/hassaku_hip.h."""
+    _lib.load().hsk_eval_set_arith(int(form))
 
 
 def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k, excl_indptr=None, excl_indices=None,

@@ -361,13 +361,20 @@ int hsk_bprmf_flush(hsk_bprmf_state* st, hsk_stream_t stream);
 int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols,
                          int64_t* u_out, int64_t* i_out, hsk_stream_t stream);
 
-/* Arithmetic of the score GEMMs of hsk_mf_eval_topk and hsk_mf_eval_topk_fused: 1 (default) = every fp32 operand cut into
- * three bf16 pieces, six bf16 MFMAs per product block -- fp32-GEMM accuracy (<= 1e-6 of the largest score against
- * float64) at 1.2-1.5x the rate; 0 = the exact-fp32 MFMA form.  Both entry points follow the switch and the same order of
- * operations, so the materialised and the fused path agree bit for bit in either form.
+/* Arithmetic of the score GEMMs of hsk_mf_eval_topk[_planes] and hsk_mf_eval_topk_fused:
+ *   2 (default)  every fp32 operand scaled by a power of two (its table's largest |x| -> [2^14, 2^15)) and cut into two fp16
+ *                pieces, three fp16 MFMAs per product block on the 256 x 256 kernels -- error against float64 at or below
+ *                that of an fp32 GEMM (<= 1e-6 of the largest score; pieces exact for every element within 2^-18 of the
+ *                table's maximum), at half the MFMAs of form 1.  Taken wherever the call brings the pieces' scratch
+ *                (hsk_mf_eval_planes_bytes / hsk_mf_eval_fused_ws_bytes_dim) and dim % 4 == 0 with 16-byte aligned
+ *                tables; any other call runs form 1;
+ *   1            three bf16 pieces per operand, six bf16 MFMAs per product block (no scaling: the whole fp32 range);
+ *   0            the exact-fp32 MFMA form.
+ * Both entry points follow the switch and the same order of operations, so for one set of arguments (scratch given to both
+ * or to neither) the materialised and the fused path agree bit for bit in every form.
  * Process-wide; the environment variable HSK_EVAL_X3 sets the initial value.  (Replaces nothing in the reference: its
- * scores are torch's fp32 matmul, eval/eval.py:240-248; both forms meet the 1e-5 bound against it.) */
-void hsk_eval_set_arith(int three_piece_bf16);
+ * scores are torch's fp32 matmul, eval/eval.py:240-248; all three forms meet the 1e-5 bound against it.) */
+void hsk_eval_set_arith(int form);
 
 /* Columns of the step's internal batch rows for a batch of this shape: n_cols, or n_cols + P - 1 when the step runs the
  * item-partitioned forward (csrc/hsk_fwd_part.h: large batches, item tables of a few L2 sizes), whose rows hold the
@@ -574,10 +581,11 @@ int hsk_mf_eval_topk(const float* user_emb, const float* item_emb, const float* 
                      int32_t* status, hsk_stream_t stream);
 
 /*
- * The same call with scratch for the operands' bf16 pieces (hsk_eval_set_arith(1), the default arithmetic): given
+ * The same call with scratch for the operands' pieces (hsk_eval_set_arith forms 1 and 2): given
  * planes_ws of >= hsk_mf_eval_planes_bytes(n_rows, item_count, dim) bytes (256-byte aligned), the rows are cut into
- * their three pieces once up front instead of once per tile inside the GEMM loop -- the same bits out.  planes_ws NULL
- * (or too small, or dim % 4 != 0): exactly hsk_mf_eval_topk.
+ * their pieces once up front instead of once per tile inside the GEMM loop -- in form 1 the same bits out; form 2 (fp16
+ * pairs) exists only on such pre-cut operands.  planes_ws NULL (or too small, or dim % 4 != 0): exactly
+ * hsk_mf_eval_topk, which runs form 1 when form 2 is set.
  */
 int64_t hsk_mf_eval_planes_bytes(int64_t n_rows, int64_t item_count, int64_t dim);
 int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_emb, const float* item_bias,
@@ -595,9 +603,10 @@ int hsk_mf_eval_topk_planes(const float* user_emb, const float* item_emb, const 
  * candidate lists, csrc/hsk_eval_fused.hip), so nothing of size n_rows x item_count is ever written -- at 131 072
  * items that matrix is 1 GB per 2048 users.  k <= 128.  ws: hsk_mf_eval_fused_ws_bytes(n_rows, item_count, k) bytes of
  * device scratch, 256-byte aligned.  out_vals / out_idx exactly as hsk_mf_eval_topk returns them.
- * hsk_mf_eval_fused_ws_bytes_dim(..., dim) is the larger size that also holds the three bf16 pieces of both operands
- * (hsk_eval_set_arith(1), the default): given that much, the call splits the rows once up front instead of once per
- * tile inside the GEMM loop -- same bits out, less work in the loop.  Either size is accepted.
+ * hsk_mf_eval_fused_ws_bytes_dim(..., dim) is the larger size that also holds the pieces of both operands
+ * (hsk_eval_set_arith forms 1 and 2): given that much, the call splits the rows once up front instead of once per
+ * tile inside the GEMM loop -- form 1: same bits out, less work in the loop; form 2 needs it (without, form 1 runs).
+ * Either size is accepted.
  */
 int64_t hsk_mf_eval_fused_ws_bytes(int64_t n_rows, int64_t item_count, int64_t k);
 int64_t hsk_mf_eval_fused_ws_bytes_dim(int64_t n_rows, int64_t item_count, int64_t k, int64_t dim);

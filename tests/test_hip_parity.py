@@ -722,14 +722,16 @@ def test_fused_topk_equals_materialised_topk(ops, shape):
     same values, same ids, same order -- with biases, exclusions (one user with fewer than k admissible items: the
     -inf entries fill up, lowest id first), exact ties (duplicated item rows) and an item range."""
     R, n_users, n_items, D, k = shape
-    # both kernels follow the same arithmetic switch and the same order of operations: bit-equal in either form
+    # both kernels follow the same arithmetic switch and the same order of operations: bit-equal in every form (form 2,
+    # the fp16-pair core, runs wherever the rows are 16-byte aligned -- both paths then take the 256 x 256 kernels -- and
+    # both fall back to form 1 together where they are not: D = 30)
     try:
-        for x3 in (False, True):
-            ops.set_eval_arith(x3)
+        for form in (ops.EVAL_ARITH_FP32, ops.EVAL_ARITH_BF16X3, ops.EVAL_ARITH_F16X2):
+            ops.set_eval_arith(form)
             _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross=False)
     finally:
-        ops.set_eval_arith(True)
-    # the two forms against each other (materialised exact-fp32 vs fused three-piece bf16): values to 4e-6 of the largest
+        ops.set_eval_arith(ops.EVAL_ARITH_DEFAULT)
+    # the forms against each other (materialised exact-fp32 vs fused in the default form): values to 4e-6 of the largest
     # score, ids wherever neighbouring scores are clearly further apart than that
     _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross=True)
 
@@ -752,17 +754,64 @@ def test_presplit_operands_equal_in_loop_split(ops, shape):
     pairs = np.argwhere(rng.rand(n_users, n_items) < min(0.05, 200.0 / n_items))
     e_ptr, e_idx = csr_from_pairs(pairs, n_users)
     u = torch.from_numpy(rng.randint(0, n_users, size=R).astype(np.int64)).cuda()
-    for lo, cnt in ((0, n_items), (n_items // 3, n_items - n_items // 3 - 7)):
-        kk = min(k, cnt)
-        for want in (True, False):
-            a = ops.mf_eval_topk(U, I, Ib, None, None, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
-                                 want_scores=want, presplit=True)
-            b = ops.mf_eval_topk(U, I, Ib, None, None, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
-                                 want_scores=want, presplit=False)
-            assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), (shape, lo, want)
-            assert torch.equal(a[1], b[1]), (shape, lo, want)
-            if want:
-                assert torch.equal(a[2][:R * cnt].view(torch.int32), b[2][:R * cnt].view(torch.int32))
+    ops.set_eval_arith(ops.EVAL_ARITH_BF16X3)   # (form 2 exists only on pre-split operands: test_f16_pair_scores_...)
+    try:
+        for lo, cnt in ((0, n_items), (n_items // 3, n_items - n_items // 3 - 7)):
+            kk = min(k, cnt)
+            for want in (True, False):
+                a = ops.mf_eval_topk(U, I, Ib, None, None, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
+                                     want_scores=want, presplit=True)
+                b = ops.mf_eval_topk(U, I, Ib, None, None, u, kk, dev(e_ptr), dev(e_idx), item_begin=lo, item_count=cnt,
+                                     want_scores=want, presplit=False)
+                assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), (shape, lo, want)
+                assert torch.equal(a[1], b[1]), (shape, lo, want)
+                if want:
+                    assert torch.equal(a[2][:R * cnt].view(torch.int32), b[2][:R * cnt].view(torch.int32))
+    finally:
+        ops.set_eval_arith(ops.EVAL_ARITH_DEFAULT)
+
+
+@pytest.mark.parametrize('case', ['init-scale', 'wide-range', 'tiny', 'huge', 'zeros-and-inf'])
+def test_f16_pair_scores_against_float64(ops, case):
+    """Form 2 of the score arithmetic (two fp16 pieces per operand at a power-of-two scale taken from the table's largest
+    |x|, three products: csrc/hsk_gemm_wide_h2.h) against float64 on the same fp32 tables, beside the exact-fp32 MFMA form:
+    its error stays within 4x the fp32 form's own (both are dominated by the fp32 accumulation; measured 0.8-2x) and far inside north_star's
+    1e-5 of the largest score -- for tables at the reference's init scale (std 0.1 / D), with per-column scales spread over
+    three decades, with magnitudes near the ends of the fp32 range, and with zero rows / an infinite entry."""
+    R, n_users, n_items, D = 300, 300, 3000, 128
+    g = torch.Generator(device='cuda').manual_seed(23)
+    U = torch.randn(n_users, D, device='cuda', generator=g)
+    I = torch.randn(n_items, D, device='cuda', generator=g)
+    if case == 'init-scale':
+        U, I = U * (0.1 / D), I * (0.1 / D)
+    elif case == 'wide-range':
+        cs = torch.exp(torch.randn(D, device='cuda', generator=g) * 2.3)
+        U, I = U * cs, I * cs
+    elif case == 'tiny':
+        U, I = U * 1e-17, I * 1e-15
+    elif case == 'huge':
+        U, I = U * 3e12, I * 1e14
+    else:
+        U[5] = 0.0
+        I[7] = 0.0
+        I[11, 3] = float('inf')
+    u = torch.arange(R, device='cuda', dtype=torch.int64)
+    out = {}
+    try:
+        for form in (ops.EVAL_ARITH_FP32, ops.EVAL_ARITH_F16X2):
+            ops.set_eval_arith(form)
+            out[form] = ops.mf_eval_topk(U, I, None, None, None, u, 10, want_scores=True)[2][:R * n_items].view(R, n_items).double()
+    finally:
+        ops.set_eval_arith(ops.EVAL_ARITH_DEFAULT)
+    ref = U.double() @ I.double().T
+    fin = torch.isfinite(ref)
+    scale = ref[fin].abs().max().item()
+    err = {f: ((o - ref)[fin].abs().max().item()) for f, o in out.items()}
+    assert err[ops.EVAL_ARITH_F16X2] <= max(4.0 * err[ops.EVAL_ARITH_FP32], 5e-7 * scale), (case, err, scale)
+    assert err[ops.EVAL_ARITH_F16X2] <= 2e-6 * scale, (case, err, scale)
+    if case == 'zeros-and-inf':   # the infinite entry: nothing finite in its column (inf or nan, as in fp32); zero row: zeros
+        assert not torch.isfinite(out[ops.EVAL_ARITH_F16X2][:, 11]).any()
+        assert (out[ops.EVAL_ARITH_F16X2][5][fin[5]] == 0).all()
 
 
 def _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross):
@@ -770,7 +819,7 @@ def _fused_vs_materialised(ops, R, n_users, n_items, D, k, cross):
 
     def arith(materialised):   # cross: the materialised reference in exact fp32, the fused path in the default form
         if cross:
-            ops.set_eval_arith(not materialised)
+            ops.set_eval_arith(ops.EVAL_ARITH_FP32 if materialised else ops.EVAL_ARITH_DEFAULT)
 
     g = torch.Generator(device='cuda').manual_seed(7)
     U = torch.randn(n_users, D, device='cuda', generator=g) * 0.3
