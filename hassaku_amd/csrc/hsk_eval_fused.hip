@@ -638,18 +638,37 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
   const float gbv = gb ? gb[0] : 0.f;
 
   constexpr int KPL = FGW_CAP / 64;   // keys per lane of a compaction
+  // MSB-first radix select of the k-th largest key, 8 bits per pass.  Two things keep it to ~2 passes instead of 8: the
+  // digits every live key shares (the keys of one row are scores of about one magnitude: sign, exponent and a few mantissa
+  // bits agree, and a pass over such a digit is 640 LDS atomics on ONE counter) are taken from the keys' maximum and
+  // minimum without a pass, and the passes stop as soon as the selected bin is taken whole (its members differ only below
+  // the digits already fixed: nothing left to decide).  The threshold is the smallest key kept -- exact either way.
   auto compact_row = [&](int rloc) {   // one wave, one row with n > k candidates: keep the best k, raise thr
     const int n = cnt[rloc];
     if (n <= k) return;
     unsigned long long kv[KPL];
+    unsigned long long kmax = 0ull, kmin = ~0ull;
 #pragma unroll
     for (int m = 0; m < KPL; ++m) {
       const int j = lane + 64 * m;
       kv[m] = (j < n) ? cand[(long long)rloc * FGW_CAP + j] : 0ull;
+      if (kv[m] != 0ull) {
+        kmax = kv[m] > kmax ? kv[m] : kmax;
+        kmin = kv[m] < kmin ? kv[m] : kmin;
+      }
     }
-    unsigned long long prefix = 0ull, pmask = 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long a = __shfl_xor(kmax, off, 64), b = __shfl_xor(kmin, off, 64);
+      kmax = a > kmax ? a : kmax;
+      kmin = b < kmin ? b : kmin;
+    }
+    const unsigned long long diff = kmax ^ kmin;   // (n > k >= 1 distinct keys: diff != 0)
+    const int first = __builtin_clzll(diff | 1ull) >> 3;   // passes 0 .. first - 1: every live key has the maximum's digit
+    unsigned long long pmask = first ? ~0ull << (64 - 8 * first) : 0ull;
+    unsigned long long prefix = kmax & pmask;
     int need = k;
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = first; pass < 8; ++pass) {
       const int shift = 56 - 8 * pass;
 #pragma unroll
       for (int q = 0; q < 4; ++q) hist[lane * 4 + q] = 0u;
@@ -667,35 +686,46 @@ __global__ __launch_bounds__(256, 1) void k_score_topk_wide(
         if (lane + off < 64) above += t;
       }
       above -= mine;
-      int found_digit = -1, found_need = 0;
+      int found_digit = -1, found_need = 0, found_cnt = 0;
       {
         int a3 = above, a2 = above + (int)c3, a1 = a2 + (int)c2, a0 = a1 + (int)c1;
-        if (a3 < need && need <= a3 + (int)c3) { found_digit = lane * 4 + 3; found_need = need - a3; }
-        else if (a2 < need && need <= a2 + (int)c2) { found_digit = lane * 4 + 2; found_need = need - a2; }
-        else if (a1 < need && need <= a1 + (int)c1) { found_digit = lane * 4 + 1; found_need = need - a1; }
-        else if (a0 < need && need <= a0 + (int)c0) { found_digit = lane * 4; found_need = need - a0; }
+        if (a3 < need && need <= a3 + (int)c3) { found_digit = lane * 4 + 3; found_need = need - a3; found_cnt = (int)c3; }
+        else if (a2 < need && need <= a2 + (int)c2) { found_digit = lane * 4 + 2; found_need = need - a2; found_cnt = (int)c2; }
+        else if (a1 < need && need <= a1 + (int)c1) { found_digit = lane * 4 + 1; found_need = need - a1; found_cnt = (int)c1; }
+        else if (a0 < need && need <= a0 + (int)c0) { found_digit = lane * 4; found_need = need - a0; found_cnt = (int)c0; }
       }
       const unsigned long long who = __ballot(found_digit >= 0);
       const int src = __builtin_ctzll(who);
       const int digit = __shfl(found_digit, src, 64);
       need = __shfl(found_need, src, 64);
+      const int whole = __shfl(found_cnt, src, 64);
       prefix |= (unsigned long long)digit << shift;
       pmask |= 0xffull << shift;
+      if (need == whole) break;   // the bin is kept whole: keys >= prefix (zeros below) are exactly the k best
     }
     int base = 0;
+    unsigned long long kth = ~0ull;
 #pragma unroll
     for (int m = 0; m < KPL; ++m) {
       const bool keep = kv[m] >= prefix && kv[m] != 0ull;
       const unsigned long long bm = __ballot(keep);
-      if (keep) cand[(long long)rloc * FGW_CAP + base + __popcll(bm & ((1ull << lane) - 1ull))] = kv[m];
+      if (keep) {
+        cand[(long long)rloc * FGW_CAP + base + __popcll(bm & ((1ull << lane) - 1ull))] = kv[m];
+        kth = kv[m] < kth ? kv[m] : kth;
+      }
       base += __popcll(bm);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long b = __shfl_xor(kth, off, 64);
+      kth = b < kth ? b : kth;
     }
     if (lane == 0) {
       cnt[rloc] = k;
-      const uint32_t kth = (uint32_t)(prefix >> 32);
-      const float told = thr[rloc], tnew = fg_key2f(kth);
+      const uint32_t kth32 = (uint32_t)(kth >> 32);
+      const float told = thr[rloc], tnew = fg_key2f(kth32);
       thr[rloc] = (tnew < told) ? told : tnew;           // (the shared threshold may already be above this list's k-th)
-      if (gthr) atomicMax(&gthr[m0 + rloc], kth);
+      if (gthr) atomicMax(&gthr[m0 + rloc], kth32);
     }
     __builtin_amdgcn_wave_barrier();
   };
