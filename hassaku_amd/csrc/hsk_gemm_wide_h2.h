@@ -101,36 +101,44 @@ __device__ __forceinline__ void hsk_h2_kloop(hsk_w_f32x16 (&acc)[4][4], hsk_h2_s
     };
     // per k16 tile the three products of weight >= 2^-11, smallest first: (lo, hi) (hi, lo) (hi, hi)
     constexpr int TK[6] = {0, 0, 0, 1, 1, 1}, TA[6] = {1, 0, 0, 1, 0, 0}, TB[6] = {0, 1, 0, 0, 1, 0};
-    read_a(0, 1, 0, 4);
+    read_a(0, 1, 0, 1);   // (in the order the first MFMAs want them: the first one waits for two reads, not five)
     read_b(0, 0, 0, 4);
+    read_a(0, 1, 1, 4);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NPAIR; ++c) {
+      // fragments of the coming terms, the store of the next step's chunk and the load of the one after, each behind an
+      // MFMA of its own: issued as one burst behind the chunk's six MFMAs they drained the matrix pipe's queue
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
         const int m = c * CH + q, tt = m / PER, i = (m % PER) / TN, j = m % TN;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TK[tt]][TA[tt]][i], b[TK[tt]][TB[tt]][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == 0) {
+          if (c < 8) *reinterpret_cast<hsk_w_u32x4*>(wr + hsk_h2_dst(c, tid)) = s.ra[c];
+          else *reinterpret_cast<hsk_w_u32x4*>(wr + GEMM_H_OP_STAGE + hsk_h2_dst(c - 8, tid)) = s.rb[c - 8];
+        }
+        if (q == 1) {
+          if (c < 8) s.ra[c] = *hsk_h2_src(A, tl, c, a_rows, m0, tid);
+          else s.rb[c - 8] = *hsk_h2_src(B, tl, c - 8, b_rows, n0, tid);
+        }
+        if (q == 2 || q == 3) {
+          const int lo = 2 * (q - 2);   // two fragment reads behind this MFMA
+          if (c == 0) read_a(0, 0, lo, lo + 2);
+          if (c == 1) read_b(0, 1, lo, lo + 2);
+          if (q == 2) {
+            if (c == 3) read_a(1, 1, 0, 2);
+            if (c == 4) read_a(1, 1, 2, 4);
+            if (c == 5) read_b(1, 0, 0, 2);
+            if (c == 6) read_b(1, 0, 2, 4);
+            if (c == 7) read_b(1, 1, 0, 2);
+            if (c == 8) read_b(1, 1, 2, 4);
+            if (c == 9) read_a(1, 0, 0, 2);
+            if (c == 10) read_a(1, 0, 2, 4);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // fragments of the coming terms, under the MFMAs of the running one
-      if (c == 0) read_a(0, 0, 0, 4);
-      if (c == 1) read_b(0, 1, 0, 4);
-      if (c == 3) read_a(1, 1, 0, 2);
-      if (c == 4) read_a(1, 1, 2, 4);
-      if (c == 5) read_b(1, 0, 0, 2);
-      if (c == 6) read_b(1, 0, 2, 4);
-      if (c == 7) read_b(1, 1, 0, 2);
-      if (c == 8) read_b(1, 1, 2, 4);
-      if (c == 9) read_a(1, 0, 0, 2);
-      if (c == 10) read_a(1, 0, 2, 4);
-      if (c < 8) {
-        *reinterpret_cast<hsk_w_u32x4*>(wr + hsk_h2_dst(c, tid)) = s.ra[c];
-        s.ra[c] = *hsk_h2_src(A, tl, c, a_rows, m0, tid);
-      } else {
-        *reinterpret_cast<hsk_w_u32x4*>(wr + GEMM_H_OP_STAGE + hsk_h2_dst(c - 8, tid)) = s.rb[c - 8];
-        s.rb[c - 8] = *hsk_h2_src(B, tl, c - 8, b_rows, n0, tid);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
