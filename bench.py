@@ -759,25 +759,30 @@ def run_sharded_1rank(workload, device):
 XGMI_LINK_GBS_PER_DIRECTION = 76.5   # guide: 7 links x ~153 GB/s per GPU, bidirectional -> per link and direction
 
 
-def predicted_scaling(sharded_us, item_us_guess, B, N, D):
+def predicted_scaling(sharded_us, B, N, D, U, item_us=90.0, user_update_us=55.0, small_us=15.0):
     """PREDICTION, not a measurement (no multi-GPU node has run this code): the weak-scaling step from the measured
     one-rank sharded step and the guide's link rate.  The mesh is point to point: a rank sends its C user rows to each of
     its W - 1 peers over that peer's own link, so a row exchange takes 4 D C / link rate whatever W is (C = user slots per
-    owner ~ B + 6 sigma + 8).  As built, the all_gather is exposed in full, the reduce_scatter hides under the item pass as
-    far as that lasts, the scalar reductions cost their latency.  `pipelined`: the design of MEASUREMENTS.md R4.6
-    (step t+1's rows gathered under step t on a second communicator, the ~B/W rows both batches share patched after the
-    owners' update) -- not built."""
+    owner ~ B + 6 sigma + 8).  As built: the all_gather opens the step, exposed in full; the reduce_scatter and, behind it,
+    the owners' user update run beside the item pass and are exposed by what they outlast it; two small reductions cost
+    their latency.  `pipelined`: the design of MEASUREMENTS.md R4.6 -- the rows of batch t+1 that batch t does not train
+    on are gathered during step t, only the shared ones (a fraction 1 - exp(-G / U) of them) after the owners' update --
+    not built.  Both exchanges of a step cross every link in the same direction: 2 x row_exchange_us is a floor."""
     import math
     out = {'note': 'PREDICTED from the measured 1-rank sharded step + %.1f GB/s per xGMI link and direction; weak scaling, '
                    'B = %d per rank; nothing here was measured on more than one GPU' % (XGMI_LINK_GBS_PER_DIRECTION, B),
-           'one_rank_sharded_us': sharded_us, 'item_pass_us_assumed': item_us_guess, 'small_all_reduce_us_assumed': 15.0}
+           'one_rank_sharded_us': sharded_us, 'item_pass_us_assumed': item_us, 'user_update_us_assumed': user_update_us,
+           'small_all_reduce_us_assumed': small_us}
     for W in (2, 4, 8):
         G = W * B
         C = G / W + 6.0 * math.sqrt(G / W * (1.0 - 1.0 / W)) + 8
         t_x = 4.0 * D * C / (XGMI_LINK_GBS_PER_DIRECTION * 1e3)        # us per row exchange
-        as_built = sharded_us + t_x + max(0.0, t_x - item_us_guess) + 2 * 15.0
-        piped = sharded_us - 27.0 + max(0.0, t_x - item_us_guess) + 0.1 * t_x + 2 * 15.0   # catch-up + pack + gather off the path
-        out[f'W{W}'] = {'row_exchange_us': t_x, 'step_us_as_built': as_built, 'triplets_per_s_as_built': G * N / as_built * 1e6,
+        tail = max(0.0, t_x + user_update_us - item_us)                # reduce_scatter + user update beyond the item pass
+        as_built = sharded_us + t_x + tail + 2 * small_us
+        shared = 1.0 - math.exp(-G / float(U))                         # rows of batch t+1 that batch t updates
+        piped = max(2.0 * t_x, sharded_us - 27.0 + tail + shared * t_x + 3.0 + 2 * small_us)   # catch-up + pack + gather off the path
+        out[f'W{W}'] = {'row_exchange_us': t_x, 'rows_shared_with_previous_batch': shared,
+                        'step_us_as_built': as_built, 'triplets_per_s_as_built': G * N / as_built * 1e6,
                         'step_us_pipelined_design': piped, 'triplets_per_s_pipelined_design': G * N / piped * 1e6}
     return out
 
@@ -932,8 +937,8 @@ def main():
             out['workloads']['cfg5_shard'] = children['cfg5_shard']
             out['sharded_1rank'] = children['sharded_1rank']
             if 'ms_per_step' in children['sharded_1rank']:
-                out['predicted_scaling'] = predicted_scaling(children['sharded_1rank']['ms_per_step'] * 1e3, 90.0, r['B'],
-                                                             r['N'], r['D'])
+                out['predicted_scaling'] = predicted_scaling(children['sharded_1rank']['ms_per_step'] * 1e3, r['B'], r['N'],
+                                                             r['D'], r['data'].n_users)
             out['ieee_build'] = children['ieee_build']
             # the driver's protocol to the letter: exactly --warmup steps, no sweep in front of the fence
             x = guarded(run_training, args.workload, device, args.steps, args.warmup, None, not args.no_prefetch, 'auto',
