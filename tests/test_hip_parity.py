@@ -771,14 +771,14 @@ def test_presplit_operands_equal_in_loop_split(ops, shape):
         ops.set_eval_arith(ops.EVAL_ARITH_DEFAULT)
 
 
-@pytest.mark.parametrize('case', ['init-scale', 'wide-range', 'tiny', 'huge', 'zeros-and-inf'])
+@pytest.mark.parametrize('case', ['init-scale', 'wide-range', 'tiny', 'huge', 'zeros-and-inf', 'ragged-k'])
 def test_f16_pair_scores_against_float64(ops, case):
     """Form 2 of the score arithmetic (two fp16 pieces per operand at a power-of-two scale taken from the table's largest
     |x|, three products: csrc/hsk_gemm_wide_h2.h) against float64 on the same fp32 tables, beside the exact-fp32 MFMA form:
     its error stays within 4x the fp32 form's own (both are dominated by the fp32 accumulation; measured 0.8-2x) and far inside north_star's
     1e-5 of the largest score -- for tables at the reference's init scale (std 0.1 / D), with per-column scales spread over
     three decades, with magnitudes near the ends of the fp32 range, and with zero rows / an infinite entry."""
-    R, n_users, n_items, D = 300, 300, 3000, 128
+    R, n_users, n_items, D = 300, 300, 3000, (200 if case == 'ragged-k' else 128)   # 200 -> seven k-steps of 32, the last ragged
     g = torch.Generator(device='cuda').manual_seed(23)
     U = torch.randn(n_users, D, device='cuda', generator=g)
     I = torch.randn(n_items, D, device='cuda', generator=g)
@@ -791,6 +791,8 @@ def test_f16_pair_scores_against_float64(ops, case):
         U, I = U * 1e-17, I * 1e-15
     elif case == 'huge':
         U, I = U * 3e12, I * 1e14
+    elif case == 'ragged-k':
+        U, I = U * 0.3, I * 0.3
     else:
         U[5] = 0.0
         I[7] = 0.0
