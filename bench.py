@@ -586,8 +586,13 @@ def run_eval(shape, device, comm=None, chunk=None, repeat=3):
     from hassaku_amd import hip_ops as ops
     from hassaku_amd.eval.eval import FullEvaluator
     U, I, D, npos = EVAL_SHAPES[shape]
-    if chunk is None:     # (wide catalogue: top-k inside the GEMM; narrow: materialised scores, 0.7 GB of them per chunk at ml10m)
-        chunk = int(os.environ.get('HSK_BENCH_EVAL_CHUNK', '16384'))
+    if chunk is None:
+        # eval_batch_size (the reference's conf key; the caller's choice).  Wide catalogue, top-k inside the GEMM: 16 384
+        # users.  Narrow, materialised scores: 1.5 GB of them per chunk (35 072 users at the ml10m width: the score GEMM's
+        # 256 x 256 workgroups then fill their last round of 256 CUs better and the item table is cut into its pieces twice
+        # per pass instead of five times -- 13.4 -> 14.0 M users/s against chunks of 16 384)
+        rule = 16384 if I >= ops.FUSED_TOPK_MIN_ITEMS else max(256, min(U + 255, int(1.5e9 / (4 * I))) // 256 * 256)
+        chunk = int(os.environ.get('HSK_BENCH_EVAL_CHUNK', rule))
     user_emb, item_emb, item_bias, ds = eval_problem(shape, device)
     ev = FullEvaluator(aggr_by_group=True, n_groups=0, user_to_user_group=None)
     ks = sorted(ev.K_VALUES, reverse=True)
