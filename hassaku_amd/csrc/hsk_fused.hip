@@ -1394,6 +1394,22 @@ static int hsk_pipe_step(hsk_bprmf_state* st, const hsk_ws& w_all, const hsk_bat
       a->pipe[sl].stage += 1;
     }
   }
+  // HSK_PIPE_SOLO=mask (experiments: what a rider costs its host launch): 1 sampler, 2 histogram, 4 row scan, 8 scatter,
+  // 16 bucket -- that phase (and the ones in front of it) as a launch of its own in front of the step instead of riding
+  static const int solo = getenv("HSK_PIPE_SOLO") ? atoi(getenv("HSK_PIPE_SOLO")) : 0;
+  if (solo) {
+    const int upto[3] = {(solo & 16) ? HSK_PIPE_B : 0, (solo & 8) ? HSK_PIPE_C : (solo & 4) ? HSK_PIPE_R : 0,
+                         (solo & 2) ? HSK_PIPE_H : (solo & 1) ? HSK_PIPE_S : 0};
+    const int sl3[3] = {sc, s1, s2};
+    for (int k = 0; k < 3; ++k) {
+      if (sl3[k] < 0) continue;
+      const hsk_ws w = hsk_select(w_all, sl3[k]);
+      while (a->pipe[sl3[k]].stage < upto[k]) {
+        if ((rc = hsk_pipe_launch_phase(st, w, a->pipe[sl3[k]], a->pipe[sl3[k]].stage + 1, stream))) return rc;
+        a->pipe[sl3[k]].stage += 1;
+      }
+    }
+  }
   // what rides in this step's two launches
   hsk_ride_fwd rf = {};
   hsk_ride_item ri = {};
@@ -1419,10 +1435,11 @@ static int hsk_pipe_step(hsk_bprmf_state* st, const hsk_ws& w_all, const hsk_bat
     const hsk_ws w2 = hsk_select(w_all, s2);
     const hsk_aux::pipe_slot& b = a->pipe[s2];
     if (b.stage == HSK_PIPE_NONE) {
-      rf.S = hsk_ride_sample{(int)hsk_ceil_div(b.batch, 4), st->coo_user, st->coo_item, b.order, (long long)b.start,
+      static const int s_per_wave = getenv("HSK_PIPE_S_PER_WAVE") ? std::min(64, std::max(1, atoi(getenv("HSK_PIPE_S_PER_WAVE")))) : 8;
+      rf.S = hsk_ride_sample{(int)hsk_ceil_div(b.batch, 4 * s_per_wave), st->coo_user, st->coo_item, b.order, (long long)b.start,
                              (int)b.batch, (int)b.n_neg, st->csr_indptr, st->csr_indices, (int)st->n_items, st->seed,
                              (uint64_t)b.step, w2.u32, w2.it32, w2.owner, w2.cnt, st->status,
-                             hsk_alias{st->alias_prob, st->alias_idx}, w2.stamp, n_part};
+                             hsk_alias{st->alias_prob, st->alias_idx}, w2.stamp, n_part, s_per_wave};
       a->pipe[s2].stage = HSK_PIPE_S;
     }
     if (a->pipe[s2].stage == HSK_PIPE_S) {

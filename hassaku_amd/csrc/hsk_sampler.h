@@ -68,10 +68,15 @@ struct hsk_alias {
   const int32_t* alias;
 };
 
+// bitmap (optional): the user's positives as one bit per item (LDS) -- the same test as the binary search, one read
 __device__ __forceinline__ int hsk_draw_negative(const int32_t* __restrict__ csr_indices, long long row_lo,
                                                  long long row_hi, uint32_t n_items, uint32_t b, uint32_t n,
                                                  uint64_t seed, uint64_t stream_id, int32_t* status,
-                                                 hsk_alias at = hsk_alias{nullptr, nullptr}) {
+                                                 hsk_alias at = hsk_alias{nullptr, nullptr},
+                                                 const uint32_t* __restrict__ bitmap = nullptr) {
+  auto taken = [&](int cand) {
+    return bitmap ? ((bitmap[cand >> 5] >> (cand & 31)) & 1u) != 0u : hsk_row_has(csr_indices, row_lo, row_hi, cand);
+  };
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const uint32_t thresh = (uint32_t)(-(int32_t)n_items) % n_items;  // 2^32 mod n_items
   int last = 0;
@@ -92,7 +97,7 @@ __device__ __forceinline__ int hsk_draw_negative(const int32_t* __restrict__ csr
         const float u01 = (float)(rr[a + 1] >> 8) * (1.0f / 16777216.0f);
         const int cand = (u01 < at.prob[col]) ? col : at.alias[col];
         last = cand;
-        if (!hsk_row_has(csr_indices, row_lo, row_hi, cand)) return cand;
+        if (!taken(cand)) return cand;
       }
       continue;
     }
@@ -102,11 +107,34 @@ __device__ __forceinline__ int hsk_draw_negative(const int32_t* __restrict__ csr
       if ((uint32_t)m < thresh) continue;  // biased zone: costs one attempt
       const int cand = (int)(m >> 32);
       last = cand;
-      if (!hsk_row_has(csr_indices, row_lo, row_hi, cand)) return cand;
+      if (!taken(cand)) return cand;
     }
   }
   if (status) atomicOr(status, HSK_STATUS_SAMPLER_GAVE_UP);
   return last;
+}
+
+// the draws of positive b against its user's sorted positives `set` [0, len) and the batch rows they fill
+__device__ __forceinline__ void hsk_sample_draw_write(int b, int lane, const int32_t* __restrict__ set, int len, int u, int ipos,
+                                                      int n_neg, int n_items, uint64_t seed, uint64_t stream_id,
+                                                      int* __restrict__ u32, int* __restrict__ row, int* __restrict__ owner,
+                                                      int* __restrict__ cnt, int32_t* status, int b_offset, hsk_alias at,
+                                                      int* __restrict__ stamp, int n_part,
+                                                      const uint32_t* __restrict__ bitmap = nullptr) {
+  for (int n = lane; n < n_neg; n += 64) {
+    const int neg = hsk_draw_negative(set, 0, len, (uint32_t)n_items, (uint32_t)(b + b_offset), (uint32_t)n, seed,
+                                      stream_id, status, at, bitmap);
+    row[n_part + n] = neg;
+  }
+  if (lane < n_part) row[lane] = lane ? -1 : ipos;
+  if (lane == 0) {
+    u32[b] = u;
+    if (owner) {
+      atomicMin(&owner[u], b);
+      atomicAdd(&cnt[u], 1);
+    }
+    if (stamp) stamp[u] = (int)stream_id + 1;
+  }
 }
 
 // one wave per positive (b = its batch position); lanes stride over the n_neg slots
@@ -134,20 +162,8 @@ __device__ __forceinline__ void hsk_prep_sample_body(int b, int lane, int wave, 
     __builtin_amdgcn_wave_barrier();
   }
   const int32_t* set = staged ? lds_row[wave] : csr_indices + lo;
-  for (int n = lane; n < n_neg; n += 64) {
-    const int neg = hsk_draw_negative(set, 0, len, (uint32_t)n_items, (uint32_t)(b + b_offset), (uint32_t)n, seed,
-                                      stream_id, status, at);
-    row[n_part + n] = neg;
-  }
-  if (lane < n_part) row[lane] = lane ? -1 : ipos;
-  if (lane == 0) {
-    u32[b] = u;
-    if (owner) {
-      atomicMin(&owner[u], b);
-      atomicAdd(&cnt[u], 1);
-    }
-    if (stamp) stamp[u] = (int)stream_id + 1;
-  }
+  hsk_sample_draw_write(b, lane, set, len, u, ipos, n_neg, n_items, seed, stream_id, u32, row, owner, cnt, status, b_offset, at,
+                        stamp, n_part);
 }
 
 __global__ __launch_bounds__(256) void k_prep_sample(const int32_t* __restrict__ coo_user,
@@ -198,15 +214,88 @@ struct hsk_ride_sample {
   hsk_alias at;
   int* stamp;
   int n_part;
+  int per_wave;   // positives per wave (>= 1)
 };
 
+// per_wave <= 64 positives per wave.  One positive per wave (k_prep_sample's form) puts 4096 waves in front of the host
+// launch, each a chain of four dependent loads (order -> coo -> indptr -> the user's row) before its first draw: they hold
+// EVERY wave slot of the chip for the forward's first ~6 us (measured: 6.9 us of it).  Here lane k of a wave runs that
+// chain for the wave's k-th positive -- once per wave instead of once per positive -- and the next positive's row
+// (its first 256 entries, four registers) is fetched while the current one draws: the same draws from a fraction of the
+// wave-time, in workgroups that leave the host's own most of the slots from its first microsecond.
 __device__ __forceinline__ void hsk_ride_sample_body(const hsk_ride_sample& a, int bid) {
+  __shared__ int32_t ride_row[4][HSK_SAMPLER_LDS_ROW];
   const int lane = hsk_lane();
   const int wave = hsk_uniform_i(threadIdx.x >> 6);
-  const int b = bid * 4 + wave;
-  if (b >= a.B) return;
-  hsk_prep_sample_body(b, lane, wave, a.coo_user, a.coo_item, a.order, a.start, a.n_neg, a.csr_indptr, a.csr_indices,
-                       a.n_items, a.seed, a.stream_id, a.u32, a.it32, a.owner, a.cnt, a.status, 0, a.at, a.stamp, a.n_part);
+  const int K = a.n_neg + 1;
+  // lane k: the wave's k-th positive
+  const int my_b = (lane * a.n_blocks + bid) * 4 + wave;
+  long long my_lo = 0;
+  int my_u = 0, my_ipos = 0, my_len = -1;   // (-1: no such positive)
+  if (lane < a.per_wave && my_b < a.B) {
+    const long long pos = a.order ? (long long)a.order[a.start + my_b] : (a.start + my_b);
+    my_u = a.coo_user[pos];
+    my_ipos = a.coo_item[pos];
+    my_lo = a.csr_indptr[my_u];
+    my_len = (int)(a.csr_indptr[my_u + 1] - my_lo);
+  }
+  int32_t nxt[4];
+  auto fetch = [&](int k) {   // the first 256 entries of positive k's row -> nxt
+    const int len = __shfl(my_len, k, 64);
+    const long long lo = ((long long)__shfl((int)(my_lo >> 32), k, 64) << 32) | (uint32_t)__shfl((int)my_lo, k, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nxt[j] = (lane + 64 * j < len) ? a.csr_indices[lo + lane + 64 * j] : 0;
+  };
+  // catalogues of up to 32 768 items: the wave's LDS row holds the user's positives as a BITMAP (one bit per item) -- the
+  // rejection test is then one LDS read instead of a ~7-step binary search, each step an LDS round trip.  The words a
+  // positive's row sets are cleared again behind its draws, so the bitmap is zeroed once per wave.
+  const bool bm = a.n_items <= 32 * HSK_SAMPLER_LDS_ROW;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(ride_row[wave]);
+  if (bm) {
+    for (int j = lane; j < (a.n_items + 31) / 32; j += 64) bits[j] = 0u;
+    __builtin_amdgcn_wave_barrier();
+  }
+  fetch(0);
+  for (int k = 0; k < a.per_wave; ++k) {
+    const int len = __shfl(my_len, k, 64);
+    if (len < 0) return;   // wave-uniform: positives are handed out in ascending k
+    const int b = (k * a.n_blocks + bid) * 4 + wave;
+    const int u = __shfl(my_u, k, 64), ipos = __shfl(my_ipos, k, 64);
+    const long long lo = ((long long)__shfl((int)(my_lo >> 32), k, 64) << 32) | (uint32_t)__shfl((int)my_lo, k, 64);
+    int32_t cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    const bool staged = !bm && len <= HSK_SAMPLER_LDS_ROW;
+    if (bm) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < len) atomicOr(&bits[cur[j] >> 5], 1u << (cur[j] & 31));
+      for (int j = 256 + lane; j < len; j += 64) {
+        const int it = a.csr_indices[lo + j];
+        atomicOr(&bits[it >> 5], 1u << (it & 31));
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else if (staged) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < len) ride_row[wave][lane + 64 * j] = cur[j];
+      for (int j = 256 + lane; j < len; j += 64) ride_row[wave][j] = a.csr_indices[lo + j];
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (k + 1 < a.per_wave) fetch(k + 1);   // in flight under this positive's draws
+    const int32_t* set = staged ? ride_row[wave] : a.csr_indices + lo;
+    hsk_sample_draw_write(b, lane, set, len, u, ipos, a.n_neg, a.n_items, a.seed, a.stream_id, a.u32,
+                          a.it32 + (long long)b * (K + a.n_part - 1), a.owner, a.cnt, a.status, 0, a.at, a.stamp, a.n_part,
+                          bm ? bits : nullptr);
+    __builtin_amdgcn_wave_barrier();   // (the wave's LDS row is reused by the next positive)
+    if (bm) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < len) bits[cur[j] >> 5] = 0u;
+      for (int j = 256 + lane; j < len; j += 64) bits[a.csr_indices[lo + j] >> 5] = 0u;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 }
 
 // The batches of n_group consecutive steps of a replayed run in ONE launch (graph replay only: step / start / order come

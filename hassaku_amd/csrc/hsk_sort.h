@@ -187,20 +187,42 @@ __device__ __forceinline__ void hsk_sort_scatter_body(const int* __restrict__ it
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int* run = lds + w * HSK_SORT_MAX_BUCKETS;
   const int unit = bid * 4 + w;
+  const bool live = unit < p.n_units;
+  const int lo = unit * p.epw, hi = live ? min(n_entries, lo + p.epw) : lo;
+  // every global load of the unit is issued BEFORE the scan of the bucket totals and its barrier: the unit's column of
+  // the histogram and its first 1024 entries (all of them at epw = 1024).  Behind the barrier they were two more memory
+  // round trips in a row, and a workgroup that rides in another launch holds its slots -- and slows its host -- for as
+  // long as it lives
+  int hv[HSK_SORT_MAX_BUCKETS / 64];
+#pragma unroll
+  for (int q = 0; q < HSK_SORT_MAX_BUCKETS / 64; ++q) {
+    const int d = q * 64 + lane;
+    hv[q] = (live && d < p.n_buckets) ? hist[d * p.n_units + unit] : 0;
+  }
+  int itemv[HSK_SORT_GROUP];
+#pragma unroll
+  for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+    const int e = lo + j * 64 + lane;
+    itemv[j] = (e < hi) ? it32[e] : -1;
+  }
   hsk_bucket_starts(btot, p.n_buckets, bs);
   if (bid == 0)
     for (int d = threadIdx.x; d <= p.n_buckets; d += 256) bstart[d] = bs[d];
-  if (unit >= p.n_units) return;  // no barrier below: every wave works on its own LDS row
-  for (int d = lane; d < p.n_buckets; d += 64) run[d] = bs[d] + hist[d * p.n_units + unit];
+  if (!live) return;  // no barrier below: every wave works on its own LDS row
+#pragma unroll
+  for (int q = 0; q < HSK_SORT_MAX_BUCKETS / 64; ++q) {
+    const int d = q * 64 + lane;
+    if (d < p.n_buckets) run[d] = bs[d] + hv[q];
+  }
   __builtin_amdgcn_wave_barrier();
   const int nbits = hsk_bits_for(p.n_buckets);
-  const int lo = unit * p.epw, hi = min(n_entries, lo + p.epw);
   for (int g0 = lo; g0 < hi; g0 += 64 * HSK_SORT_GROUP) {
-    int itemv[HSK_SORT_GROUP];
+    if (g0 != lo) {
 #pragma unroll
-    for (int j = 0; j < HSK_SORT_GROUP; ++j) {
-      const int e = g0 + j * 64 + lane;
-      itemv[j] = (e < hi) ? it32[e] : -1;
+      for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+        const int e = g0 + j * 64 + lane;
+        itemv[j] = (e < hi) ? it32[e] : -1;
+      }
     }
 #pragma unroll
     for (int j = 0; j < HSK_SORT_GROUP; ++j) {
