@@ -97,21 +97,27 @@ __device__ __forceinline__ void hsk_sort_hist_body(const int* __restrict__ it32,
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int* cnt = cnt_lds + w * HSK_SORT_MAX_BUCKETS;
   const int unit = bid * 4 + w;
+  const int lo = unit * p.epw, hi = unit < p.n_units ? min(n_entries, lo + p.epw) : lo;
+  // (the unit's first 1024 entries are requested before the counters are cleared: one memory round trip, not two)
+  int key[HSK_SORT_GROUP];
+#pragma unroll
+  for (int j = 0; j < HSK_SORT_GROUP; ++j) {
+    const int e = lo + j * 64 + lane;
+    key[j] = (e < hi) ? (it32[e] >> p.shift) : -1;
+  }
   for (int d = lane; d < p.n_buckets; d += 64) cnt[d] = 0;
   __syncthreads();
-  if (unit < p.n_units) {
-    const int lo = unit * p.epw, hi = min(n_entries, lo + p.epw);
-    for (int g0 = lo; g0 < hi; g0 += 64 * HSK_SORT_GROUP) {
-      int key[HSK_SORT_GROUP];
+  for (int g0 = lo; g0 < hi; g0 += 64 * HSK_SORT_GROUP) {
+    if (g0 != lo) {
 #pragma unroll
       for (int j = 0; j < HSK_SORT_GROUP; ++j) {
         const int e = g0 + j * 64 + lane;
         key[j] = (e < hi) ? (it32[e] >> p.shift) : -1;
       }
-#pragma unroll
-      for (int j = 0; j < HSK_SORT_GROUP; ++j)
-        if (key[j] >= 0) atomicAdd(&cnt[key[j]], 1);
     }
+#pragma unroll
+    for (int j = 0; j < HSK_SORT_GROUP; ++j)
+      if (key[j] >= 0) atomicAdd(&cnt[key[j]], 1);
   }
   __syncthreads();
   if (unit < p.n_units)
