@@ -471,16 +471,24 @@ def test_multi_step_call_equals_single_steps(ops, shape):
         assert np.array_equal(res[0][1][k], res[1][1][k]), k
 
 
-@pytest.mark.parametrize('lazy', [True, False])
-def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy):
+@pytest.mark.parametrize('lazy,shape', [(True, 'narrow'), (False, 'narrow'), (True, 'wide')])
+def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy, shape):
     """Large batches on the item-partitioned forward prepare the next two batches INSIDE the step's own launches (sampler
     and the item sort's phases as extra workgroups of the forward / item-user kernels, csrc/hsk_fused.hip: hsk_pipe_step)
     instead of five launches on a side stream.  Same draws, same sort, same arithmetic: tables, moments and losses equal
     the side-stream path's bit for bit -- across runs chained by hint_after_run (two batches named, one, none, a WRONG
-    one), a single step issued through the other path in between, and a flush in the middle."""
-    n_users, n_items, D, B, N = 700, 6000, 256, 2048, 17
+    one), a single step issued through the other path in between, and a flush in the middle.
+    narrow: 6000 items -- the riding sampler tests membership in an LDS bitmap; user 0 has > 256 positives (beyond the
+    prefetched registers).  wide: 40 000 items (no bitmap: the staged binary search), rows of ~400 positives, user 0 with
+    > 1024 (searched in global memory)."""
+    if shape == 'narrow':
+        n_users, n_items, D, B, N, dens, n_part = 700, 6000, 256, 2048, 17, 0.02, 2
+    else:
+        n_users, n_items, D, B, N, dens, n_part = 300, 40000, 256, 2048, 17, 0.01, 2   # (8 by size, 2 left by n_neg >= 8 P)
     rng = np.random.RandomState(9)
-    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.02)
+    mask = rng.rand(n_users, n_items) < dens
+    mask[0] = rng.rand(n_items) < (0.1 if shape == 'narrow' else 0.03)   # 600 / 1200 positives
+    pairs = np.argwhere(mask)
     pairs = pairs[rng.permutation(len(pairs))]
     ptr, idx = csr_from_pairs(pairs, n_users)
     P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
@@ -499,7 +507,7 @@ def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy):
                                  coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32),
                                  lazy_users=lazy)
             st.st.nnz = order.numel()
-            assert st.batch_columns(B, N + 1) == N + 2        # P = 2: the shape the pipeline is for
+            assert st.batch_columns(B, N + 1) == N + n_part   # the partitioned forward: the shape the pipeline is for
             s = 0
             st.hint_after_run(order, 7 * B, B, N, n_batches=2)
             st.steps_sampled(order, s * B, 7, B, N); s += 7   # cold start, tail: two batches named
