@@ -596,7 +596,7 @@ FUSED_TOPK_MIN_ITEMS = 20480   # below this many columns the materialised path i
                                # k_score_topk_wide): materialised / fused M users/s at U = 16 384 -- 16 384 items 6.85 / 6.15,
                                # 24 576: 3.88 / 4.38, 32 768: 2.98 / 3.57 (round 3's 128 x 128 selection crossed at 36 864)
 _fused_ws = {}             # device -> scratch of the fused selection, grown on demand
-_planes_ws = {}            # device -> scratch of the materialised path's bf16 pieces, grown on demand
+_planes_ws = {}            # device -> scratch of the materialised path's operand pieces (fp16 pairs or bf16 triples), grown on demand
 
 
 EVAL_ARITH_FP32, EVAL_ARITH_BF16X3, EVAL_ARITH_F16X2 = 0, 1, 2
@@ -614,7 +614,7 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
                  item_begin=0, item_count=None, scores_ws=None, status=None, item_shard=False, n_items_global=None,
                  want_scores=None, presplit=True):
     """Top-k of one item shard's masked scores.  -> (vals [R,k] f32, idx [R,k] i32 global, scores or None).
-    presplit=False withholds the scratch for the operands' bf16 pieces: the GEMM then splits every tile in its loop
+    presplit=False withholds the scratch for the operands' pieces: the GEMM then splits every tile in its loop (three bf16 pieces)
     (same bits; the form the library falls back to by itself, kept reachable for the parity test).
     want_scores=False: the selection runs inside the score GEMM and the score matrix is never formed (scores = None).
     want_scores=True (or a `scores_ws` buffer, k == 0, k > 128): the [R, item_count] matrix is materialised and
@@ -650,7 +650,7 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
         want_scores = scores_ws is not None or item_count < FUSED_TOPK_MIN_ITEMS
     if not want_scores and scores_ws is None and 1 <= k <= FUSED_TOPK_MAX_K and R > 0:
         if presplit:
-            need = lib.hsk_mf_eval_fused_ws_bytes_dim(R, item_count, k, dim)   # with room for the operands' bf16 pieces
+            need = lib.hsk_mf_eval_fused_ws_bytes_dim(R, item_count, k, dim)   # with room for the operands' pieces
         else:
             need = lib.hsk_mf_eval_fused_ws_bytes(R, item_count, k)
         if need <= 0:
@@ -684,7 +684,7 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
         p_emb -= 4 * dim * item_begin
         p_bias = None if p_bias is None else p_bias - 4 * item_begin
         n_items = n_items_global
-    # scratch for the operands' bf16 pieces (split once per call instead of once per tile in the GEMM loop)
+    # scratch for the operands' pieces (split once per call instead of once per tile in the GEMM loop)
     need = lib.hsk_mf_eval_planes_bytes(R, item_count, dim)
     planes = _planes_ws.get(dev)
     if planes is None or planes.numel() < need:
