@@ -614,8 +614,9 @@ def mf_eval_topk(user_emb, item_emb, item_bias, user_bias, global_bias, u_idx, k
                  item_begin=0, item_count=None, scores_ws=None, status=None, item_shard=False, n_items_global=None,
                  want_scores=None, presplit=True):
     """Top-k of one item shard's masked scores.  -> (vals [R,k] f32, idx [R,k] i32 global, scores or None).
-    presplit=False withholds the scratch for the operands' pieces: the GEMM then splits every tile in its loop (three bf16 pieces)
-    (same bits; the form the library falls back to by itself, kept reachable for the parity test).
+    presplit=False withholds the scratch for the operands' pieces: the GEMM then cuts every tile into three bf16 pieces in
+    its loop (form 1's bits whatever form is set; the form the library falls back to by itself, kept reachable for the
+    parity test).
     want_scores=False: the selection runs inside the score GEMM and the score matrix is never formed (scores = None).
     want_scores=True (or a `scores_ws` buffer, k == 0, k > 128): the [R, item_count] matrix is materialised and
     returned.  None (default): whichever is faster for the shard width (FUSED_TOPK_MIN_ITEMS); same results.
