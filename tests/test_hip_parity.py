@@ -471,7 +471,7 @@ def test_multi_step_call_equals_single_steps(ops, shape):
         assert np.array_equal(res[0][1][k], res[1][1][k]), k
 
 
-@pytest.mark.parametrize('lazy,shape', [(True, 'narrow'), (False, 'narrow'), (True, 'wide')])
+@pytest.mark.parametrize('lazy,shape', [(True, 'narrow'), (False, 'narrow'), (True, 'wide'), (False, 'narrow-popular')])
 def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy, shape):
     """Large batches on the item-partitioned forward prepare the next two batches INSIDE the step's own launches (sampler
     and the item sort's phases as extra workgroups of the forward / item-user kernels, csrc/hsk_fused.hip: hsk_pipe_step)
@@ -480,7 +480,9 @@ def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy, shape):
     one), a single step issued through the other path in between, and a flush in the middle.
     narrow: 6000 items -- the riding sampler tests membership in an LDS bitmap; user 0 has > 256 positives (beyond the
     prefetched registers).  wide: 40 000 items (no bitmap: the staged binary search), rows of ~400 positives, user 0 with
-    > 1024 (searched in global memory)."""
+    > 1024 (searched in global memory).  narrow-popular: the `popular` strategy (alias table) through the riding sampler."""
+    popular = shape.endswith('popular')
+    shape = shape.split('-')[0]
     if shape == 'narrow':
         n_users, n_items, D, B, N, dens, n_part = 700, 6000, 256, 2048, 17, 0.02, 2
     else:
@@ -503,9 +505,13 @@ def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy, shape):
     try:
         for pipelined in (True, False):
             lib.hsk_bprmf_set_pipeline(1 if pipelined else 0)
+            alias = None
+            if popular:
+                pr, al = ops.build_alias_table(np.bincount(pairs[:, 1], minlength=n_items).astype(np.float64) ** 0.75 + 1e-3)
+                alias = (dev(pr), dev(al))
             st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
                                  coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32),
-                                 lazy_users=lazy)
+                                 lazy_users=lazy, alias=alias)
             st.st.nnz = order.numel()
             assert st.batch_columns(B, N + 1) == N + n_part   # the partitioned forward: the shape the pipeline is for
             s = 0
