@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ v
                                                      int n_parts, int rows, int k, int npad,
                                                      float* __restrict__ out_vals, int32_t* __restrict__ out_idx,
                                                      int pw = 0) {
-  __shared__ unsigned long long cand[4096];
+  extern __shared__ unsigned long long merge_keys[];   // npad keys (a fixed 4096 held a CU to five rows at a time)
   const int r = blockIdx.x;
   if (pw <= 0) pw = k;
   const int total = n_parts * pw;
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ v
       const long long src = ((long long)p * rows + r) * pw + j;
       v = ((unsigned long long)fg_f2key(vals[src]) << 32) | (uint32_t)(~(uint32_t)idx[src]);
     }
-    cand[c] = v;
+    merge_keys[c] = v;
   }
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -945,17 +945,17 @@ __global__ __launch_bounds__(256) void k_fused_merge(const float* __restrict__ v
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
         const bool desc = ((lo & size) == 0);
-        const unsigned long long a = cand[lo], b = cand[hi];
+        const unsigned long long a = merge_keys[lo], b = merge_keys[hi];
         if ((a < b) == desc) {
-          cand[lo] = b;
-          cand[hi] = a;
+          merge_keys[lo] = b;
+          merge_keys[hi] = a;
         }
       }
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < k; c += 256) {
-    const unsigned long long v = cand[c];
+    const unsigned long long v = merge_keys[c];
     out_vals[(long long)r * k + c] = fg_key2f((uint32_t)(v >> 32));
     out_idx[(long long)r * k + c] = (int32_t)(~(uint32_t)v);
   }
@@ -1151,8 +1151,8 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
       if (SW > 1) {
         int npad = 1;
         while (npad < SW * pw) npad <<= 1;
-        k_fused_merge<<<(unsigned)n_rows, 256, 0, stream>>>(part_vals, part_idx, SW, (int)n_rows, (int)k, npad, out_vals,
-                                                            out_idx, pw);
+        k_fused_merge<<<(unsigned)n_rows, 256, (size_t)npad * 8, stream>>>(part_vals, part_idx, SW, (int)n_rows, (int)k, npad,
+                                                                           out_vals, out_idx, pw);
         HSK_LAUNCH_CHECK();
       }
       return HSK_OK;
@@ -1203,8 +1203,8 @@ extern "C" int hsk_mf_eval_topk_fused(const float* user_emb, const float* item_e
   if (S > 1) {
     int npad = 1;
     while (npad < S * (int)k) npad <<= 1;
-    k_fused_merge<<<(unsigned)n_rows, 256, 0, stream>>>(part_vals, part_idx, S, (int)n_rows, (int)k, npad, out_vals,
-                                                        out_idx);
+    k_fused_merge<<<(unsigned)n_rows, 256, (size_t)npad * 8, stream>>>(part_vals, part_idx, S, (int)n_rows, (int)k, npad,
+                                                                       out_vals, out_idx);
     HSK_LAUNCH_CHECK();
   }
   return HSK_OK;
