@@ -496,7 +496,7 @@ def roofline_of(workload, r):
         bound, peak = 'l2', L2_GATHER_GBS
         kernel = ('k_fwd_part, P = %d (gather + scores + BPR + partial user-row grads; the next batch\'s lazy user rows brought up to '
                   'date by workgroups of the same launch; the launch also carries the sampler of batch t+2 and two sort phases of '
-                  'batches t / t+1 -- avg_us includes them, pure_gather does not)') % parts
+                  'batches t / t+1: about 2.5 us of avg_us, MEASUREMENTS.md R4.2b)') % parts
         peak_source = ('MI355X_MICROARCH.md, "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs\' L2s (mid-point); '
                        'each XCD gathers from %.1f MB of the %.1f MB item table' % (table_mb / parts, table_mb))
     elif r.get('sharded') and table_mb / W <= 4.0:
