@@ -55,7 +55,9 @@ static inline int64_t hsk_part_cols(int64_t n_cols, int n_part) { return n_cols 
 static int hsk_part_rule(int64_t n_items, int64_t dim, int64_t batch, int64_t n_neg, bool lazy_items) {
   static const int env = getenv("HSK_FWD_PARTS") ? atoi(getenv("HSK_FWD_PARTS")) : 0;
   if (env == 1 || lazy_items) return 1;
-  if (dim % 256 != 0 || dim > 2048 || batch < 2048 || n_neg > 256 || n_items < 64) return 1;
+  // (the partitioned kernel exists for rows of 64 lanes x 4 floats x {1, 2, 4, 8} whole chunks: 256, 512, 1024, 2048 --
+  // 768 passed the old `dim % 256 == 0` test and then found no kernel: tools/stress_pipeline.py)
+  if ((dim != 256 && dim != 512 && dim != 1024 && dim != 2048) || batch < 2048 || n_neg > 256 || n_items < 64) return 1;
   int P;
   if (env == 2 || env == 4 || env == 8) {
     P = env;
@@ -457,6 +459,9 @@ struct hsk_aux {
   int64_t pf_start = 0, pf_batch = 0, pf_nneg = 0, pf_step = 0;
   int cur_set = 0;  // buffers of the batch of the latest step
   int cur_slot = 0; // ... and its slot inside the set (grouped preparation; 0 otherwise)
+  // the same for hsk_bprmf_last_batch / _last_sort: cur_set is folded back into {0, 1} when the pipeline is reset (a flush),
+  // what the debug reads want is where the last step's batch still sits
+  int last_set = 0, last_slot = 0;
   bool grouped = false;   // capture of a run with grouped preparation: the steps launch no prefetch of their own
   // graph capture context: while `g_desc` is set the launch sequence is being CAPTURED, not run: kernels take their
   // per-step scalars from the device descriptor + the relative step `g_rel`, launches carry no events of their own
@@ -962,8 +967,8 @@ static int hsk_run_step(hsk_bprmf_state* st, const hsk_ws& w_all, int set, bool 
   hsk_aux* aux = (hsk_aux*)st->aux;
   const bool gen = st->opt_kind != HSK_OPT_ADAMW;   // generic optimiser arithmetic instead of the AdamW-only kernels
   if (aux) {
-    aux->cur_set = set;
-    aux->cur_slot = slot;
+    aux->cur_set = aux->last_set = set;
+    aux->cur_slot = aux->last_slot = slot;
   }
   if (!sorted) {
     int src = hsk_launch_sort(st, w, total, stream);
@@ -1787,6 +1792,8 @@ extern "C" int hsk_bprmf_train_steps(hsk_bprmf_state* st, const int64_t* order, 
           aux->cur_set = (n & 1) ? set0 : (set0 ^ 1);
           aux->cur_slot = 0;
         }
+        aux->last_set = aux->cur_set;
+        aux->last_slot = aux->cur_slot;
       }
       s += n;
       // lazily updated rows: the periodic sweeps that came due during the replayed run follow it (the cadence is a speed
@@ -1845,7 +1852,7 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   if ((rc = hsk_check_batch(st, batch, n_cols))) return rc;
   hsk_ws w = hsk_carve_st(st);
   const int64_t total = batch * n_cols;
-  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set, ((hsk_aux*)st->aux)->cur_slot);
+  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->last_set, ((hsk_aux*)st->aux)->last_slot);
   // partitioned row layout: the positive sits in n_part columns, the caller sees it once
   const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0);
   k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
@@ -1866,7 +1873,7 @@ extern "C" int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries,
   HSK_REQUIRE(perm_out && offsets_out && n_entries > 0 && n_entries <= st->max_batch * (st->max_cols + HSK_PART_MAX - 1),
               HSK_ERR_INVALID, "bad argument");
   hsk_ws w = hsk_carve_st(st);
-  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->cur_set, ((hsk_aux*)st->aux)->cur_slot);
+  if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->last_set, ((hsk_aux*)st->aux)->last_slot);
   HSK_HIP(hipMemcpyAsync(perm_out, w.perm, n_entries * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
   HSK_HIP(hipMemcpyAsync(offsets_out, w.offsets, (st->n_items + 1) * sizeof(int), hipMemcpyDeviceToDevice,
                          (hipStream_t)stream_));

@@ -471,6 +471,60 @@ def test_multi_step_call_equals_single_steps(ops, shape):
         assert np.array_equal(res[0][1][k], res[1][1][k]), k
 
 
+@pytest.mark.parametrize('n_steps', [6, 7, 8])
+def test_last_batch_after_a_flush_of_a_pipelined_run(ops, n_steps):
+    """hsk_bprmf_last_batch after a flush returns the batch of the last step whichever of the pipeline's three buffer sets
+    it sat in (the flush folds the running set index back into {0, 1}; found by tools/stress_pipeline.py)."""
+    n_users, n_items, D, B, N = 500, 6000, 256, 2048, 17
+    rng = np.random.RandomState(4)
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.02)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
+    order = torch.from_numpy(rng.permutation(len(pairs))).cuda()
+    lib = ops._lib.load()
+    got = []
+    try:
+        for pipelined in (True, False):
+            lib.hsk_bprmf_set_pipeline(1 if pipelined else 0)
+            st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                                 coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+            st.hint_after_run(order, n_steps * B, B, N, n_batches=2)
+            st.steps_sampled(order, 0, n_steps, B, N)
+            st.flush()
+            bu, bi = st.last_batch(B, N + 1)
+            got.append((bu.cpu().numpy(), bi.cpu().numpy()))
+    finally:
+        lib.hsk_bprmf_set_pipeline(1)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert np.array_equal(got[0][0], pairs[order.cpu().numpy()[(n_steps - 1) * B: n_steps * B], 0])
+
+
+def test_large_batch_at_dim_768_takes_the_unpartitioned_forward(ops):
+    """D = 768 is a multiple of 256 but not a whole number of the partitioned kernel's chunk counts (1, 2, 4, 8): a large
+    batch on a mid-size item table must fall back to the un-partitioned forward, not fail (found by
+    tools/stress_pipeline.py: 'item-partitioned forward selected for dim 768')."""
+    n_users, n_items, D, B, N = 300, 4000, 768, 2048, 17          # item table 12.3 MB: the partition rule's range
+    rng = np.random.RandomState(2)
+    pairs = np.argwhere(rng.rand(n_users, n_items) < 0.02)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ptr, idx = csr_from_pairs(pairs, n_users)
+    P = {'user_emb': (rng.randn(n_users, D) * 0.05).astype(np.float32),
+         'item_emb': (rng.randn(n_items, D) * 0.05).astype(np.float32),
+         'item_bias': (rng.randn(n_items) * 0.1).astype(np.float32)}
+    order = torch.from_numpy(rng.permutation(len(pairs))).cuda()
+    st, t = _fused_state(ops, P, 1e-3, 1e-4, B, N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
+                         coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32))
+    assert st.batch_columns(B, N + 1) == N + 1
+    st.steps_sampled(order, 0, 3, B, N)
+    st.flush()
+    st.check_status()
+    assert np.isfinite(st.last_loss()) and st.pipelined_steps() == 0
+    assert np.isfinite(t['item_emb'].cpu().numpy()).all()
+
+
 @pytest.mark.parametrize('lazy,shape', [(True, 'narrow'), (False, 'narrow'), (True, 'wide'), (False, 'narrow-popular')])
 def test_in_launch_pipeline_equals_side_stream_prefetch(ops, lazy, shape):
     """Large batches on the item-partitioned forward prepare the next two batches INSIDE the step's own launches (sampler
