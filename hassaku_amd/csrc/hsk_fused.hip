@@ -71,6 +71,12 @@ static int hsk_part_rule(int64_t n_items, int64_t dim, int64_t batch, int64_t n_
   while (P > 1 && n_neg < 8 * P) P >>= 1;
   return P;
 }
+// ... for a state: no partitions under lazy item AdamW, nor under sampled softmax (the partitioned kernel carries the bpr and
+// bce epilogues only -- a sampled-softmax run with a large batch on a mid-size item table ran the bpr one:
+// tests/stress_step.py)
+static int hsk_part_rule_st(const hsk_bprmf_state* st, int64_t batch, int64_t n_neg) {
+  return hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0 || st->loss_kind == HSK_LOSS_SSM);
+}
 
 // =============================================================================================
 // workspace carving
@@ -806,7 +812,7 @@ static int hsk_launch_prep_sample(const hsk_bprmf_state* st, const hsk_ws& w, co
                                   int64_t batch, int64_t n_neg, uint64_t stream_id, hipStream_t stream) {
   const hsk_aux* ax = (const hsk_aux*)st->aux;
   const hsk_step_desc* desc = ax ? ax->g_desc : nullptr;
-  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0);
+  const int n_part = hsk_part_rule_st(st, batch, n_neg);
   // capture: `stream_id` arrives as the relative step of the batch being prepared
   HSK_STAGE(HSK_STAGE_PREP, k_prep_sample<<<(unsigned)hsk_ceil_div(batch, 4), 256, 0, stream>>>(
                                 st->coo_user, st->coo_item, order, start, (int)batch, (int)n_neg, st->csr_indptr,
@@ -930,8 +936,7 @@ static int hsk_launch_prefetch(hsk_bprmf_state* st, const hsk_ws& w_all, int set
   int prc = hsk_launch_prep_sample(st, wn, aux->hint_order, aux->hint_start, aux->hint_batch, aux->hint_nneg,
                                    aux->g_desc ? (uint64_t)(aux->g_rel + 1) : (uint64_t)st->step, aux->side);
   if (!prc) {
-    const int64_t tot = aux->hint_batch * hsk_part_cols(aux->hint_nneg + 1, hsk_part_rule(st->n_items, st->dim, aux->hint_batch,
-                                                                                         aux->hint_nneg, st->lazy_items != 0));
+    const int64_t tot = aux->hint_batch * hsk_part_cols(aux->hint_nneg + 1, hsk_part_rule_st(st, aux->hint_batch, aux->hint_nneg));
     prc = hsk_launch_sort(st, wn, tot, aux->side);
   }
   if (prc) return prc;
@@ -1256,7 +1261,7 @@ struct hsk_batch_desc {
 
 static bool hsk_pipe_plan(const hsk_bprmf_state* st, int64_t batch, int64_t n_neg, int* n_part_out, hsk_sort_plan* plan,
                           int64_t* total_out) {
-  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0);
+  const int n_part = hsk_part_rule_st(st, batch, n_neg);
   const int64_t total = batch * hsk_part_cols(n_neg + 1, n_part);
   if (n_part_out) *n_part_out = n_part;
   if (total_out) *total_out = total;
@@ -1488,7 +1493,7 @@ extern "C" int hsk_bprmf_train_step(hsk_bprmf_state* st, const int64_t* u_idx, c
   if ((rc = hsk_discard_prefetch(st, w, stream))) return rc;
   const int set = st->aux ? (((hsk_aux*)st->aux)->cur_set ^ 1) : 0;
   const hsk_ws ws = hsk_select(w, set);
-  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0);
+  const int n_part = hsk_part_rule_st(st, batch, n_cols - 1);
   HSK_STAGE(HSK_STAGE_PREP, k_prep_external<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, stream>>>(
                                 u_idx, i_idx, (int)batch, (int)n_cols, (int)st->n_users, (int)st->n_items, ws.u32,
                                 ws.it32, ws.owner, ws.cnt, st->status, ws.stamp, (int)st->step + 1, n_part));
@@ -1510,7 +1515,7 @@ extern "C" int hsk_bprmf_train_step_sampled(hsk_bprmf_state* st, const int64_t* 
   // the RNG stream id is the index of the step about to be taken: every step draws fresh negatives
   st->timing_now = st->timing && (st->timing_every <= 1 || ((st->step + 1) % st->timing_every) == 0);
   hsk_aux* aux = (hsk_aux*)st->aux;
-  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0);
+  const int n_part = hsk_part_rule_st(st, batch, n_neg);
   if ((rc = hsk_pipe_reset(st, w, stream))) return rc;
   if (aux && aux->pf_valid && aux->pf_order == order && aux->pf_start == start && aux->pf_batch == batch &&
       aux->pf_nneg == n_neg && aux->pf_step == st->step) {
@@ -1670,7 +1675,7 @@ static int hsk_capture_steps(hsk_bprmf_state* st, const hsk_ws& w, int64_t n, in
     }
     if (rc == HSK_OK)
       rc = hsk_run_step(st, w, set, sorted, batch, K, stream,
-                        hsk_part_rule(st->n_items, st->dim, batch, n_neg, st->lazy_items != 0));
+                        hsk_part_rule_st(st, batch, n_neg));
     set ^= 1;
   }
   const hipError_t e = hipStreamEndCapture(stream, &graph);
@@ -1854,7 +1859,7 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
   const int64_t total = batch * n_cols;
   if (st->aux) w = hsk_select(w, ((hsk_aux*)st->aux)->last_set, ((hsk_aux*)st->aux)->last_slot);
   // partitioned row layout: the positive sits in n_part columns, the caller sees it once
-  const int n_part = hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0);
+  const int n_part = hsk_part_rule_st(st, batch, n_cols - 1);
   k_widen_batch<<<(unsigned)hsk_ceil_div(total, 256), 256, 0, (hipStream_t)stream_>>>(w.u32, w.it32, batch, total,
                                                                                       u_out, i_out, (int)n_cols, n_part);
   HSK_LAUNCH_CHECK();
@@ -1863,7 +1868,7 @@ extern "C" int hsk_bprmf_last_batch(const hsk_bprmf_state* st, int64_t batch, in
 
 extern "C" int64_t hsk_bprmf_batch_columns(const hsk_bprmf_state* st, int64_t batch, int64_t n_cols) {
   if (!st || batch <= 0 || n_cols < 2) return -1;
-  return hsk_part_cols(n_cols, hsk_part_rule(st->n_items, st->dim, batch, n_cols - 1, st->lazy_items != 0));
+  return hsk_part_cols(n_cols, hsk_part_rule_st(st, batch, n_cols - 1));
 }
 
 extern "C" int hsk_bprmf_last_sort(const hsk_bprmf_state* st, int64_t n_entries, int32_t* perm_out, int32_t* offsets_out,

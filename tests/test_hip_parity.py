@@ -227,6 +227,32 @@ def test_fused_step_vs_oracle_random_shapes(ops, oracle, D, U, I, B, N):
     st.check_status()
 
 
+@pytest.mark.parametrize('loss', ['sampled_softmax', 'bce', 'bpr'])
+def test_large_batch_on_a_mid_size_item_table_vs_oracle(ops, oracle, loss):
+    """B = 2048 on an 8 MB item table: the shape the item-partitioned forward is for.  It carries the bpr and bce epilogues;
+    sampled softmax must take the un-partitioned kernel (it ran the bpr epilogue there until tests/stress_step.py found it:
+    loss 35.3 against 9.26)."""
+    D, U, I, B, N = 256, 400, 8000, 2048, 17
+    rng = np.random.RandomState(12)
+    P = {'user_emb': (rng.randn(U, D) * 0.1).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.1).astype(np.float32),
+         'item_bias': (rng.randn(I) * 0.1).astype(np.float32)}
+    lr, wd = 1e-3, 4e-5
+    adj = float(np.log(I / N)) if loss == 'sampled_softmax' else 0.0
+    st, t = _fused_state(ops, P, lr, wd, B, N + 1, loss=loss, log_adjust=adj)
+    assert st.batch_columns(B, N + 1) == (N + 1 if loss == 'sampled_softmax' else N + 2)
+    tr = oracle.MfOracleTrainer(P['user_emb'], P['item_emb'], P['item_bias'], lr=lr, wd=wd, loss=loss, log_adjust=adj)
+    for step in range(2):
+        u = rng.randint(0, U, size=B).astype(np.int64)
+        i = rng.randint(0, I, size=(B, N + 1)).astype(np.int64)
+        st.step(dev(u), dev(i))
+        loss_ref = tr.step(u, i)[0]
+        assert abs(st.last_loss() - loss_ref) <= 1e-6 * abs(loss_ref), (step, st.last_loss(), loss_ref)
+    st.flush()
+    for name in P:
+        assert_adam_param_close(t[name].cpu().numpy(), tr.P[name], name)
+    st.check_status()
+
+
 def test_bad_index_is_flagged_not_fatal(ops):
     U = torch.randn(10, 16, device='cuda')
     I = torch.randn(12, 16, device='cuda')
