@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Randomised check of the sharded multi-rank step against the single-GPU step (test infrastructure; not collected):
+    python tests/stress_dist.py [seconds] [seed] [world]          (on a GPU box; the ranks share GPU 0)
+`world` processes over gloo, the natively issued step (hsk_shard_step) on the host-staged collective table or the phased
+step; random shapes (D, negatives, table sizes, per-rank batch), losses, lazy / dense item AdamW, with and without the
+ahead-of-time preparation, a wrong next-batch guess now and then.  Rank 0 compares the gathered tables and the losses with
+BprMfFusedState on the same global batches (same seed / order / step numbering -> the same samples) under the tolerance
+rules of tests/conftest.py."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def _dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dt) if dt else t).cuda()
+
+
+def worker(rank, world, port, budget, seed):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from conftest import assert_adam_param_close, csr_from_pairs
+    from hassaku_amd import hip_ops as ops
+    from hassaku_amd.dist import Comm, ShardedBprMf
+    comm = Comm()
+    rng = np.random.RandomState(seed)          # the same stream on every rank
+    t_end = time.time() + budget
+    n = bad = skipped = 0
+    while True:
+        go = torch.tensor([1 if time.time() < t_end else 0])
+        dist.broadcast(go, 0)
+        if not int(go.item()):
+            break
+        D = int(rng.choice([8, 30, 33, 64, 100, 128, 256, 402, 512]))
+        N = int(rng.choice([1, 3, 12, 20, 50]))
+        U, I = int(rng.randint(40, 600)), int(rng.randint(N + 30, 1500))
+        B = int(rng.choice([8, 32, 48, 100, 256]))
+        loss = str(rng.choice(['bpr', 'bpr', 'bce', 'sampled_softmax']))
+        lazy_items = ['auto', True, False][int(rng.randint(3))]
+        prefetch = bool(rng.rand() < 0.7)
+        native = 'host-staged' if rng.rand() < 0.7 else False
+        n_steps = int(rng.randint(3, 30))
+        pairs = np.argwhere(rng.rand(U, I) < min(0.3, 25.0 / I))
+        wrong_at = int(rng.randint(0, n_steps))
+        P = {'user_emb': (rng.randn(U, D) * 0.05).astype(np.float32), 'item_emb': (rng.randn(I, D) * 0.05).astype(np.float32),
+             'item_bias': (rng.randn(I) * 0.1).astype(np.float32)}
+        G = world * B
+        if len(pairs) < 2 * G:
+            continue
+        pairs = pairs[rng.permutation(len(pairs))]
+        desc = dict(D=D, N=N, U=U, I=I, B=B, loss=loss, lazy_items=lazy_items, prefetch=prefetch, native=native, n_steps=n_steps)
+        ptr, idx = csr_from_pairs(pairs, U)
+        adj = float(np.log(I / N)) if loss == 'sampled_softmax' else 0.0
+        order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
+        n_slices = len(pairs) // G
+        t = {k: _dev(v) for k, v in P.items()}
+        failed = None
+        try:
+            sh = ShardedBprMf(comm, t['user_emb'], t['item_emb'], t['item_bias'], None, None, lr=2e-3, wd=1e-4, batch=B, n_neg=N,
+                              csr_indptr=_dev(ptr), csr_indices=_dev(idx), coo_user=_dev(pairs[:, 0], torch.int32),
+                              coo_item=_dev(pairs[:, 1], torch.int32), seed=77, lazy_items=lazy_items, prefetch=prefetch,
+                              native=native, loss=loss, log_adjust=adj)
+            losses = []
+            for s in range(n_steps):
+                nxt = ((s + 1) % n_slices) * G if s + 1 < n_steps else None
+                if s == wrong_at:
+                    nxt = 0
+                sh.step_sampled(order, (s % n_slices) * G, next_start=nxt)
+                losses.append(sh.last_loss())
+            sh.check_status()
+            full_u, _ = sh.gather_user_table()
+            full_i, full_ib = sh.gather_item_table()
+            sh.close()
+        except RuntimeError as e:          # a capacity overflow is raised on every rank alike: not a parity case
+            failed = str(e)[:200]
+        flag = torch.tensor([1 if failed else 0])
+        dist.all_reduce(flag)
+        if int(flag.item()):
+            skipped += 1
+            if rank == 0 and skipped <= 5:
+                print('skipped', desc, failed, flush=True)
+            continue
+        if rank == 0:
+            n += 1
+            tt = {k: _dev(v) for k, v in P.items()}
+            st = ops.BprMfFusedState(tt['user_emb'], tt['item_emb'], tt['item_bias'], None, None, lr=2e-3, wd=1e-4, max_batch=G,
+                                     max_cols=N + 1, seed=77, csr_indptr=_dev(ptr), csr_indices=_dev(idx),
+                                     coo_user=_dev(pairs[:, 0], torch.int32), coo_item=_dev(pairs[:, 1], torch.int32),
+                                     lazy_items=lazy_items, loss=loss, log_adjust=adj)
+            ref_losses = []
+            for s in range(n_steps):
+                st.step_sampled(order, (s % n_slices) * G, G, N)
+                ref_losses.append(st.last_loss())
+            st.flush()
+            try:
+                np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-5)
+                assert_adam_param_close(full_u.cpu().numpy(), tt['user_emb'].cpu().numpy(), 'user_emb')
+                assert_adam_param_close(full_i.cpu().numpy(), tt['item_emb'].cpu().numpy(), 'item_emb')
+                assert_adam_param_close(full_ib.cpu().numpy(), tt['item_bias'].cpu().numpy(), 'item_bias')
+            except AssertionError as e:
+                bad += 1
+                print('FAIL', desc, str(e)[:300].replace('\n', ' '), flush=True)
+    if rank == 0:
+        print(f'{n} cases at world {world}, {skipped} skipped (refused / overflow), {bad} failures', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0 and bad:
+        sys.exit(1)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    world = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(worker, args=(world, port, budget, seed), nprocs=world, join=True)
+
+
+if __name__ == '__main__':
+    main()
