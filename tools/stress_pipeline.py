@@ -39,6 +39,8 @@ def one_case(rng, lib):
     B = int(rng.choice([2048, 3072, 4096]))
     N = int(rng.choice([16, 17, 33, 64, 100]))
     popular = rng.rand() < 0.3
+    loss = str(rng.choice(['bpr', 'bpr', 'bce', 'sampled_softmax']))      # (sampled softmax: no pipeline, both arms alike)
+    opt = str(rng.choice(['adamw', 'adamw', 'adam', 'adagrad']))
     lazy = rng.rand() < 0.6
     per_user = rng.choice([20, 120, 400])
     dens = per_user / n_items
@@ -77,7 +79,8 @@ def one_case(rng, lib):
         st = ops.BprMfFusedState(t['user_emb'], t['item_emb'], t['item_bias'], None, None, lr=1e-3, wd=1e-4, max_batch=B,
                                  max_cols=N + 1, seed=5, csr_indptr=dev(ptr), csr_indices=dev(idx),
                                  coo_user=dev(pairs[:, 0], torch.int32), coo_item=dev(pairs[:, 1], torch.int32),
-                                 lazy_users=lazy, alias=alias)
+                                 lazy_users=lazy, alias=alias, loss=loss, optimizer=opt,
+                                 log_adjust=float(np.log(n_items / N)) if loss == 'sampled_softmax' else 0.0)
         st.st.nnz = order.numel()
         s = 0
         for m, hint in runs:
@@ -116,7 +119,7 @@ def one_case(rng, lib):
         if not np.array_equal(res[0][1][k], res[1][1][k]):
             diff.append((k, int((res[0][1][k] != res[1][1][k]).sum())))
     ok = not diff
-    desc = dict(diff=diff, D=D, n_items=n_items, n_users=n_users, B=B, N=N, popular=popular, lazy=lazy, runs=runs, pipelined_steps=res[0][5])
+    desc = dict(diff=diff, loss=loss, opt=opt, D=D, n_items=n_items, n_users=n_users, B=B, N=N, popular=popular, lazy=lazy, runs=runs, pipelined_steps=res[0][5])
     return ok, desc
 
 
