@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check that the in-launch preparation pipeline (csrc/hsk_fused.hip: hsk_pipe_step; the riding sampler with its
 LDS bitmap / staged search, the riding sort phases) trains exactly like the side-stream prefetch:
-    python tools/stress_pipeline.py [seconds] [seed]          (on a GPU box)
+    python tools/stress_pipeline.py [seconds] [seed] [dims, e.g. 1024,2048]          (on a GPU box)
 For random shapes inside the pipeline's range (D % 256 == 0, batch >= 2048, item table 4.5 .. 48 MB), random row lengths
 (some users far beyond the prefetched 256 entries / the 1024-entry LDS row), uniform or popular sampling, lazy or dense
 user AdamW and a random pattern of runs and hints: tables, moments, losses and the last batch, bit for bit."""
@@ -31,8 +31,8 @@ def csr_from_pairs(pairs, n_rows):
     return np.cumsum(indptr), cols.astype(np.int32)
 
 
-def one_case(rng, lib):
-    D = int(rng.choice([256, 512, 768]))
+def one_case(rng, lib, dims=(256, 512, 768)):
+    D = int(rng.choice(list(dims)))
     mb = float(rng.uniform(5.0, 40.0))
     n_items = int(mb * (1 << 20) / (4 * D))
     n_users = int(rng.randint(200, 1500))
@@ -126,13 +126,14 @@ def one_case(rng, lib):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    dims = tuple(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 else (256, 512, 768)
     rng = np.random.RandomState(seed)
     lib = ops._lib.load()
     t_end = time.time() + budget
     n = bad = piped = 0
     try:
         while time.time() < t_end:
-            ok, desc = one_case(rng, lib)
+            ok, desc = one_case(rng, lib, dims)
             n += 1
             piped += desc['pipelined_steps']
             if not ok:
