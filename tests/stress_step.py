@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity of the fused training step against the oracle (test infrastructure; not collected by pytest):
-    python tests/stress_step.py [seconds] [seed]          (on a GPU box)
+    python tests/stress_step.py [seconds] [seed] [big]          (on a GPU box; big: only the partitioned forward's shapes)
 Random shapes (D 2 .. 2048 of every alignment, batches 1 .. 4500, 1 .. 200 negatives, random table sizes), losses
 (bpr / bce / sampled_softmax), optimisers (adamw / adam / adagrad), bias sets, lazy or dense AdamW, duplicate users /
 items in a batch; 2-3 steps on caller-given batches, then loss, parameters and moments against oracle.MfOracleTrainer
@@ -24,15 +24,20 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def one_case(rng):
+def one_case(rng, big=False):
     D = int(rng.choice([2, 6, 16, 30, 33, 64, 100, 128, 200, 256, 384, 402, 512, 640, 768, 1024, 1280, 2048]))
     B = int(rng.choice([1, 5, 17, 64, 128, 300, 1030, 2048, 2100, 4096, 4500]))
+    if big:   # the item-partitioned forward's range: whole-chunk rows, batches >= 2048, a 4.5 .. 48 MB item table
+        D = int(rng.choice([256, 512, 1024, 2048]))
+        B = int(rng.choice([2048, 2100, 3000, 4096]))
     N = int(rng.choice([1, 3, 8, 9, 20, 50, 100, 200]))
     while B * (N + 1) * D > 5e8:                  # keep the oracle's dense step in seconds
         B = max(1, B // 2)
     U = int(rng.randint(max(2, B // 50), 3000))
     I = int(rng.randint(max(N + 2, 250), 20000))   # (the rule's 0.5 % of elements needs a few hundred of them)
-    while (U + I) * D > 6e7:
+    if big:
+        I = int(rng.uniform(5.0, 40.0) * (1 << 20) / (4 * D))
+    while (U + I) * D > 6e7 and not big:
         U, I = max(2, U // 2), max(N + 2, I // 2)
     loss = str(rng.choice(['bpr', 'bpr', 'bce', 'sampled_softmax']))
     opt = str(rng.choice(['adamw', 'adamw', 'adam', 'adagrad']))
@@ -90,12 +95,13 @@ def one_case(rng):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    big = len(sys.argv) > 3 and sys.argv[3] == 'big'
     rng = np.random.RandomState(seed)
     orc.build()
     t_end = time.time() + budget
     n = bad = refused = 0
     while time.time() < t_end:
-        ok, desc = one_case(rng)
+        ok, desc = one_case(rng, big)
         if ok is None:
             refused += 1
             if refused <= 5:
