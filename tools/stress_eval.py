@@ -2,7 +2,8 @@
 """Randomised cross-check of the evaluation paths (run on a GPU box: python tools/stress_eval.py [seconds] [seed]).
 For random shapes (rows, users, items, D, k, item range, exclusions, biases) and every arithmetic form:
   * fused top-k (no score matrix) == materialised top-k, values / ids / order, bit for bit;
-  * materialised scores against float64 within 4e-6 of the largest score.
+  * materialised scores against float64 within 4e-6 of the largest score;
+  * in 30 % of the cases: the item range handed over as a physical shard (item_shard=True) gives the same top-k.
 Prints one line per case that fails and a summary; exit code 1 on any failure."""
 import sys
 import time
@@ -53,7 +54,8 @@ def main():
                 p, i = csr_from_pairs(pairs, n_users)
                 e_ptr, e_idx = torch.from_numpy(p).cuda(), torch.from_numpy(i).cuda()
         u = torch.from_numpy(rng.randint(0, n_users, size=R).astype(np.int64)).cuda()
-        what = dict(n_users=n_users, n_items=n_items, D=D, R=R, lo=lo, cnt=cnt, k=k, scale=scale, Ib=Ib is not None,
+        shard = bool(rng.rand() < 0.3)
+        what = dict(shard=shard, n_users=n_users, n_items=n_items, D=D, R=R, lo=lo, cnt=cnt, k=k, scale=scale, Ib=Ib is not None,
                     Ub=Ub is not None, gb=gb is not None, excl=e_ptr is not None)
         for form in (ops.EVAL_ARITH_F16X2, ops.EVAL_ARITH_BF16X3, ops.EVAL_ARITH_FP32):
             ops.set_eval_arith(form)
@@ -61,6 +63,13 @@ def main():
             v1, i1, _ = ops.mf_eval_topk(U, I, Ib, Ub, gb, u, k, e_ptr, e_idx, item_begin=lo, item_count=cnt, want_scores=False)
             n_case += 1
             ok = torch.equal(v0.view(torch.int32), v1.view(torch.int32)) and torch.equal(i0, i1)
+            if shard:   # the same range handed over as a PHYSICAL shard (the library gets a virtual base and must never
+                # read outside the shard's rows): same top-k, materialised and fused
+                Is, Ibs = I[lo:lo + cnt].contiguous(), (None if Ib is None else Ib[lo:lo + cnt].contiguous())
+                for want in (True, False):
+                    v2, i2, _ = ops.mf_eval_topk(U, Is, Ibs, Ub, gb, u, k, e_ptr, e_idx, item_begin=lo, item_count=cnt,
+                                                 item_shard=True, n_items_global=n_items, want_scores=want)
+                    ok = ok and torch.equal(v0.view(torch.int32), v2.view(torch.int32)) and torch.equal(i0, i2)
             ref = U[u].double() @ I[lo:lo + cnt].double().T
             if Ub is not None:
                 ref += Ub[u].double()[:, None]
