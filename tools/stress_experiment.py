@@ -44,11 +44,20 @@ def one_case(rng, root):
     conf['max_patience'] = int(rng.randint(1, conf['n_epochs']))
     if conf['train_batch_size'] == 1 and nnz > 3000:
         conf['train_batch_size'] = 3               # (one positive per step: keep the run in seconds)
+    alg = str(rng.choice(['mf', 'mf', 'mf', 'sgdbias', 'uprotomf', 'iprotomf', 'uiprotomf', 'acf']))
+    conf.update(n_prototypes=int(rng.choice([2, 5, 20])), sim_proto_weight=float(rng.choice([0.0, 1e-3, 1.0])),
+                sim_batch_weight=float(rng.choice([0.0, 1e-3, 1.0])), u_n_prototypes=int(rng.choice([2, 7])),
+                i_n_prototypes=int(rng.choice([3, 9])), u_sim_proto_weight=1e-3, u_sim_batch_weight=1e-3,
+                i_sim_proto_weight=1e-3, i_sim_batch_weight=1e-3, n_anchors=int(rng.choice([2, 10])),
+                delta_exc=float(rng.choice([0.0, 1e-2])), delta_inc=float(rng.choice([0.0, 1e-2])))
+    if alg != 'mf':
+        conf['embedding_dim'] = int(rng.choice([2, 7, 16, 30, 64]))
+        conf['train_batch_size'] = int(rng.choice([7, 64, 128, 1000]))   # (autograd models: keep the run in seconds)
     desc = {k: conf[k] for k in ('embedding_dim', 'train_batch_size', 'neg_train', 'rec_loss', 'optimizer', 'train_neg_strategy',
                                  'eval_batch_size', 'use_user_bias', 'use_item_bias', 'use_global_bias', 'n_epochs')}
-    desc.update(n_users=n_users, n_items=n_items, nnz=nnz, groups=groups)
+    desc.update(alg=alg, n_users=n_users, n_items=n_items, nnz=nnz, groups=groups)
     try:
-        best, test, conf2 = run_train_val_test(AlgorithmsEnum.mf, DatasetsEnum.ml100k, dict(conf))
+        best, test, conf2 = run_train_val_test(AlgorithmsEnum[alg], DatasetsEnum.ml100k, dict(conf))
         bad = []
         for name, d in (('val', best), ('test', test)):
             for k, v in d.items():
