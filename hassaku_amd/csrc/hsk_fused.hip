@@ -657,6 +657,37 @@ static int hsk_launch_flush(hsk_bprmf_state* st, const hsk_ws& w, hipStream_t st
                                                          st->m_user_bias, st->v_user_bias, w.last_step, U, D,         \
                                                          (int)st->step, c, w.adam_tab, HSK_ADAM_TAB_LEN, g_poison)
   const bool gen = st->opt_kind != HSK_OPT_ADAMW;
+  // one wave per row (k_row_flush_wave) wherever a row fits a wave's registers; HSK_FLUSH_WAVE=0: workgroup per row
+  static const int wave_on = getenv("HSK_FLUSH_WAVE") ? atoi(getenv("HSK_FLUSH_WAVE")) : 1;
+  const bool wave = wave_on && D <= 64 * 8 * ((D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1);
+  auto wave_sweep = [&](float* P, float* M, float* V_, float* Pb, float* Mb, float* Vb, int* last, int n_rows) {
+    return hsk_dispatch_dim(D, [&](auto v_, auto n_, auto f_) {
+      constexpr int V = decltype(v_)::value, NCH = decltype(n_)::value;
+      constexpr bool FULL = decltype(f_)::value;
+      const unsigned grid = (unsigned)((n_rows + 3) / 4);
+      if (gen)
+        k_row_flush_wave<V, NCH, FULL, true><<<grid, 256, 0, stream>>>(P, M, V_, Pb, Mb, Vb, last, n_rows, D, (int)st->step, c,
+                                                                     w.adam_tab, HSK_ADAM_TAB_LEN, g_poison);
+      else
+        k_row_flush_wave<V, NCH, FULL, false><<<grid, 256, 0, stream>>>(P, M, V_, Pb, Mb, Vb, last, n_rows, D, (int)st->step, c,
+                                                                      w.adam_tab, HSK_ADAM_TAB_LEN, g_poison);
+      return HSK_OK;
+    });
+  };
+  if (wave) {
+    if (st->lazy_users && (which & 1)) {
+      const int rc = wave_sweep(st->user_emb, st->m_user_emb, st->v_user_emb, st->user_bias, st->m_user_bias, st->v_user_bias,
+                                w.last_step, U);
+      if (rc != HSK_OK) return rc;
+    }
+    if (st->lazy_items && (which & 2)) {
+      const int rc = wave_sweep(st->item_emb, st->m_item_emb, st->v_item_emb, st->item_bias, st->m_item_bias, st->v_item_bias,
+                                w.last_step_i, (int)st->n_items);
+      if (rc != HSK_OK) return rc;
+    }
+    HSK_LAUNCH_CHECK();
+    return HSK_OK;
+  }
   if (st->lazy_users && (which & 1)) {
     if (D % 2 == 0) {
       if (gen) HSK_FLUSH(2, true); else HSK_FLUSH(2, false);

@@ -1042,6 +1042,56 @@ __global__ __launch_bounds__(256) void k_user_flush(float* __restrict__ Uw, floa
   }
 }
 
+// The same sweep with one WAVE per table row (lane l holds (c*64 + l)*V .. +V of chunk c, hsk_rows.h): 16-byte accesses
+// and all three operands of a row in flight per wave -- at D = 512 a CU keeps 32 rows = 192 KB outstanding against the
+// 8 x 6 KB of the workgroup-per-row form, which is what a sweep bounded by HBM latency x bytes in flight wants.  Every
+// element sees the operations of k_user_flush in the same order (hsk_adamw_replay over the same constants): same bits.
+template <int V, int NCH, bool FULL, bool GEN>
+__global__ __launch_bounds__(256) void k_row_flush_wave(float* __restrict__ Uw, float* __restrict__ mU,
+                                                        float* __restrict__ vU, float* __restrict__ Ub,
+                                                        float* __restrict__ mUb, float* __restrict__ vUb,
+                                                        int* __restrict__ last_step, int n_rows, int D, int step,
+                                                        hsk_adamw_consts c, const float2* __restrict__ tab, int tab_len,
+                                                        const int* __restrict__ g_poison = nullptr) {
+  if (hsk_guard_skip(nullptr, g_poison)) return;
+  const int lane = hsk_lane();
+  const int row = blockIdx.x * 4 + hsk_uniform_i(threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int done = hsk_uniform_i(last_step[row]);
+  if (done >= step) return;
+  float* prow = Uw + (long long)row * D;
+  float* mrow = mU + (long long)row * D;
+  float* vrow = vU + (long long)row * D;
+  hsk_row<V, NCH> p, m, v;
+  hsk_row_load<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_load<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_load<V, NCH, FULL>(v, vrow, lane, D);
+  for (int t0 = done + 1; t0 <= step; t0 += 64) {
+    const float2 blk = hsk_consts_block(tab, tab_len, t0);
+    const int nt = min(64, step - t0 + 1);
+    for (int j = 0; j < nt; ++j) {
+      const hsk_adamw_consts ct = hsk_consts_lane(c, blk, j);
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+        for (int q = 0; q < V; ++q) hsk_adamw_replay<GEN>(p.c[cc].v[q], m.c[cc].v[q], v.c[cc].v[q], ct);
+    }
+  }
+  hsk_row_store<V, NCH, FULL>(p, prow, lane, D);
+  hsk_row_store<V, NCH, FULL>(m, mrow, lane, D);
+  hsk_row_store<V, NCH, FULL>(v, vrow, lane, D);
+  if (lane == 0) {
+    if (Ub) {
+      float pb = Ub[row], mb = mUb[row], vb = vUb[row];
+      for (int t = done + 1; t <= step; ++t) hsk_adamw_update<GEN>(pb, mb, vb, 0.f, hsk_consts_at(c, tab, tab_len, t));
+      Ub[row] = pb;
+      mUb[row] = mb;
+      vUb[row] = vb;
+    }
+    last_step[row] = step;
+  }
+}
+
 // tail: deterministic fp64 reduction of the per-positive loss sums; global-bias zero-grad AdamW step
 __global__ __launch_bounds__(1024) void k_finish_step(const double* __restrict__ loss_b, int B, double inv_bn,
                                                       double* __restrict__ loss_out, float* gb, float* mgb,
