@@ -303,6 +303,20 @@ def test_lazy_user_adamw_is_bitwise_the_dense_sweep(ops):
         assert np.array_equal(dense[k], lazy[k]), k
 
 
+@pytest.mark.parametrize('D', [33, 130, 402, 512, 640, 1536, 2048])
+@pytest.mark.parametrize('opt', ['adamw', 'adam'])
+def test_closing_sweep_is_bitwise_the_dense_sweep_over_row_shapes(ops, D, opt):
+    """The closing sweep runs one wave per row (k_row_flush_wave) wherever a row fits a wave's registers: every register
+    tile (1 / 2 / 4 floats per lane, 1 .. 8 chunks, whole and ragged last chunk) against dense AdamW / Adam with L2 decay
+    on every row, every step -- most rows reach the sweep with pending steps (30 steps of 24 out of 500 users)."""
+    kw = dict(U=500, I=64, D=D, B=24, N=3, optimizer=opt)
+    dense, l0 = _run_random_steps(ops, 30, lazy=False, **kw)
+    lazy, l1 = _run_random_steps(ops, 30, lazy=True, **kw)
+    assert l0 == l1
+    for k in dense:
+        assert np.array_equal(dense[k], lazy[k]), (k, D)
+
+
 @pytest.mark.parametrize('opt', ['adamw', 'adagrad'])
 def test_lazy_item_adamw_is_bitwise_the_dense_update(ops, opt):
     """lazy_items: item rows outside the batch keep their zero-gradient steps until they are next touched or flushed --
