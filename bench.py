@@ -81,6 +81,18 @@ def pmc_traffic(kernel_prefix, workload):
     return None, None
 
 
+def pmc_fetch_bytes(kernel_prefix, workload):
+    """Fabric-side READ bytes of one launch (FETCH_SIZE x 2, see pmc_traffic) from the committed profile, or None."""
+    d = PROFILE_DIR.get(workload)
+    path = os.path.join(REPO, 'profiles', d or '', 'pmc_summary.json')
+    if not d or not os.path.isfile(path):
+        return None
+    for name, row in json.load(open(path)).items():
+        if name.startswith(kernel_prefix) and 'FETCH_SIZE_KB_mean' in row:
+            return 2.0 * row['FETCH_SIZE_KB_mean'] * 1024.0
+    return None
+
+
 def init_tables(U, I, D, device, seed=64):
     torch.manual_seed(seed)
     user_emb = torch.empty((U, D), device=device).normal_(std=0.1 / D)   # train/utils.py:12-13 of the reference
@@ -523,6 +535,17 @@ def roofline_of(workload, r):
            'item_table_MB': table_mb}
     if parts > 1:
         out['frac_of_infinity_cache_gather_8600'] = achieved / ICACHE_GATHER_GBS
+        fetch = pmc_fetch_bytes('k_fwd_part', workload)
+        if fetch and fetch < by:
+            # A MODEL, not a measurement of this run: the XCD's partition (table / P) is larger than its 4 MB L2, so part of
+            # the gathered bytes misses the L2 and crosses the fabric from the Infinity Cache.  Bytes the counters saw on
+            # the fabric side priced at the guide's Infinity-Cache gather rate, the rest at its L2 gather rate:
+            t_mixed = fetch / (ICACHE_GATHER_GBS * 1e9) + (by - fetch) / (L2_GATHER_GBS * 1e9)
+            out['mixed_l2_fabric_model'] = {
+                'l2_miss_share': fetch / by, 'floor_us': t_mixed * 1e6, 'frac': t_mixed / (r['fwd_us'] * 1e-6),
+                'pure_gather_frac': (t_mixed / (r['pure_us'] * 1e-6)) if r.get('pure_us') else None,
+                'note': 'arithmetic from the committed profile\'s FETCH_SIZE (x2) and the guide\'s two gather rates; `frac` above, '
+                        'against the all-hits L2 rate, stays the quoted roofline fraction'}
     if not cached:
         out['frac_of_measured_hbm_gather_5750'] = achieved / HBM_GATHER_GBS
     if r.get('pure_us'):
