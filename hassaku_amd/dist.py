@@ -639,21 +639,28 @@ class ShardedBprMf:
 
         return gather(self.user_emb), (None if self.user_bias is None else gather(self.user_bias))
 
+    def _gather_item_rows(self, t):
+        """all_gather of one per-item tensor of the item shards -> its full [I, ...] form."""
+        W, I = self.comm.world, self.n_items
+        n_max = max(item_range(I, r, W)[1] - item_range(I, r, W)[0] for r in range(W))
+        pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        out = torch.empty((W * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.comm.all_gather_into(out, pad)
+        return torch.cat([out[r * n_max: r * n_max + item_range(I, r, W)[1] - item_range(I, r, W)[0]]
+                          for r in range(W)], dim=0)
+
     def gather_item_table(self):
         """Full [I, D] item table (and [I] item bias): the all_gather of the item shards."""
         self.flush()
-        W, I = self.comm.world, self.n_items
-        n_max = max(item_range(I, r, W)[1] - item_range(I, r, W)[0] for r in range(W))
+        return (self._gather_item_rows(self.item_emb),
+                None if self.item_bias is None else self._gather_item_rows(self.item_bias))
 
-        def gather(t):
-            pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            pad[:t.shape[0]] = t
-            out = torch.empty((W * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            self.comm.all_gather_into(out, pad)
-            return torch.cat([out[r * n_max: r * n_max + item_range(I, r, W)[1] - item_range(I, r, W)[0]]
-                              for r in range(W)], dim=0)
-
-        return gather(self.item_emb), (None if self.item_bias is None else gather(self.item_bias))
+    def gather_item_moments(self):
+        """Full [I, D] exp_avg and exp_avg_sq of the item table (diagnostics: a parameter that differs between two
+        summation orders while both moments agree is Adam's division at work, tests/conftest.py)."""
+        self.flush()
+        return self._gather_item_rows(self.m['item_emb']), self._gather_item_rows(self.v['item_emb'])
 
 
 class TableShards:
