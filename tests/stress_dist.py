@@ -55,7 +55,7 @@ def worker(rank, world, port, budget, seed):
     comm = Comm()
     rng = np.random.RandomState(seed)          # the same stream on every rank
     t_end = time.time() + budget
-    n = bad = skipped = n_eval = amplified = 0
+    n = bad = skipped = n_eval = amplified = redo = 0
     while True:
         go = torch.tensor([1 if time.time() < t_end else 0])
         dist.broadcast(go, 0)
@@ -85,16 +85,15 @@ def worker(rank, world, port, budget, seed):
         adj = float(np.log(I / N)) if loss == 'sampled_softmax' else 0.0
         order = torch.from_numpy(np.random.RandomState(1).permutation(len(pairs))).cuda()
         n_slices = len(pairs) // G
-        t = {k: _dev(v) for k, v in P.items()}
-        failed = None
-        try:
+        def run_sharded(k_steps, with_eval):
+            t = {k: _dev(v) for k, v in P.items()}
             sh = ShardedBprMf(comm, t['user_emb'], t['item_emb'], t['item_bias'], None, None, lr=2e-3, wd=1e-4, batch=B, n_neg=N,
                               csr_indptr=_dev(ptr), csr_indices=_dev(idx), coo_user=_dev(pairs[:, 0], torch.int32),
                               coo_item=_dev(pairs[:, 1], torch.int32), seed=77, lazy_items=lazy_items, prefetch=prefetch,
                               native=native, loss=loss, log_adjust=adj)
             losses = []
-            for s in range(n_steps):
-                nxt = ((s + 1) % n_slices) * G if s + 1 < n_steps else None
+            for s in range(k_steps):
+                nxt = ((s + 1) % n_slices) * G if s + 1 < k_steps else None
                 if s == wrong_at:
                     nxt = 0
                 sh.step_sampled(order, (s % n_slices) * G, next_start=nxt)
@@ -104,10 +103,28 @@ def worker(rank, world, port, budget, seed):
             full_i, full_ib = sh.gather_item_table()
             full_mi, full_vi = sh.gather_item_moments()
             metrics = None
-            if do_eval:
+            if with_eval:
                 metrics = evaluate_item_sharded(comm, sh, _EvalDs(pairs, val, U, I),
                                                 FullEvaluator(aggr_by_group=False, n_groups=0, user_to_user_group=None), chunk=64)
             sh.close()
+            return losses, full_u, full_i, full_ib, full_mi, full_vi, metrics
+
+        def run_single(k_steps):
+            tt = {k: _dev(v) for k, v in P.items()}
+            st = ops.BprMfFusedState(tt['user_emb'], tt['item_emb'], tt['item_bias'], None, None, lr=2e-3, wd=1e-4, max_batch=G,
+                                     max_cols=N + 1, seed=77, csr_indptr=_dev(ptr), csr_indices=_dev(idx),
+                                     coo_user=_dev(pairs[:, 0], torch.int32), coo_item=_dev(pairs[:, 1], torch.int32),
+                                     lazy_items=lazy_items, loss=loss, log_adjust=adj)
+            ref_losses = []
+            for s in range(k_steps):
+                st.step_sampled(order, (s % n_slices) * G, G, N)
+                ref_losses.append(st.last_loss())
+            st.flush()
+            return st, tt, ref_losses
+
+        failed = None
+        try:
+            losses, full_u, full_i, full_ib, full_mi, full_vi, metrics = run_sharded(n_steps, do_eval)
         except RuntimeError as e:          # a capacity overflow is raised on every rank alike: not a parity case
             failed = str(e)[:200]
         flag = torch.tensor([1 if failed else 0])
@@ -119,16 +136,7 @@ def worker(rank, world, port, budget, seed):
             continue
         if rank == 0:
             n += 1
-            tt = {k: _dev(v) for k, v in P.items()}
-            st = ops.BprMfFusedState(tt['user_emb'], tt['item_emb'], tt['item_bias'], None, None, lr=2e-3, wd=1e-4, max_batch=G,
-                                     max_cols=N + 1, seed=77, csr_indptr=_dev(ptr), csr_indices=_dev(idx),
-                                     coo_user=_dev(pairs[:, 0], torch.int32), coo_item=_dev(pairs[:, 1], torch.int32),
-                                     lazy_items=lazy_items, loss=loss, log_adjust=adj)
-            ref_losses = []
-            for s in range(n_steps):
-                st.step_sampled(order, (s % n_slices) * G, G, N)
-                ref_losses.append(st.last_loss())
-            st.flush()
+            st, tt, ref_losses = run_single(n_steps)
             try:
                 np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-5)
                 assert_adam_param_close(full_u.cpu().numpy(), tt['user_emb'].cpu().numpy(), 'user_emb')
@@ -161,8 +169,26 @@ def worker(rank, world, port, budget, seed):
                           str(e)[:300].replace('\n', ' '), flush=True)
                 else:
                     bad += 1
+                    redo = 1
                     print('FAIL (item exp_avg %.1e, exp_avg_sq %.1e)' % (em, ev), desc, str(e)[:300].replace('\n', ' '),
                           flush=True)
+        # a failing case once more, step count by step count: where the two runs part (every rank takes part)
+        redo_t = torch.tensor([redo if rank == 0 else 0])
+        dist.broadcast(redo_t, 0)
+        redo = 0
+        if int(redo_t.item()):
+            for k_steps in range(1, n_steps + 1):
+                _, f_u, f_i, _, f_mi, f_vi, _ = run_sharded(k_steps, False)
+                if rank == 0:
+                    st, tt, _ = run_single(k_steps)
+                    worst = int((f_i - tt['item_emb']).abs().argmax().item())
+                    worst_u = int((f_u - tt['user_emb']).abs().argmax().item())
+                    print('  trace: %2d steps  item_emb %.1e (row %d col %d)  exp_avg %.1e  exp_avg_sq %.1e   user_emb %.1e (row %d '
+                          'col %d)' % (
+                              k_steps, max_norm_err(f_i.cpu().numpy(), tt['item_emb'].cpu().numpy()), worst // D, worst % D,
+                              max_norm_err(f_mi.cpu().numpy(), st.m['item_emb'].cpu().numpy()),
+                              max_norm_err(f_vi.cpu().numpy(), st.v['item_emb'].cpu().numpy()),
+                              max_norm_err(f_u.cpu().numpy(), tt['user_emb'].cpu().numpy()), worst_u // D, worst_u % D), flush=True)
     if rank == 0:
         print(f'{n} cases at world {world} ({n_eval} with the item-sharded evaluation), {skipped} skipped (refused / overflow), '
               f'{amplified} parameter outliers with agreeing moments, {bad} failures', flush=True)
