@@ -56,7 +56,7 @@ L2_GATHER_GBS = 17800.0      # same table: rows shared by every workgroup of an 
 HBM_GATHER_GBS = 5750.0      # same guide: random 2.3 KB rows of a table far beyond the Infinity Cache, 5.7-5.8 TB/s
 MFMA_FP32_TFLOPS = 157.0     # exact-fp32 MFMA peak (v_mfma_f32_32x32x2_f32; no xf32 on gfx950)
 MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-PROFILE_DIR = {'ml10m': 'r4c_ml10m', 'hbm': 'r4_hbm', 'ml1m': 'r4_ml1m', 'ml100k': 'r4_ml100k'}  # committed rocprofv3 summaries (PMC passes)
+PROFILE_DIR = {'ml10m': 'r4c_ml10m', 'hbm': 'r4c_hbm', 'ml1m': 'r4_ml1m', 'ml100k': 'r4_ml100k'}  # committed rocprofv3 summaries (PMC passes)
 LR, WD = 3e-4, 4e-5          # README.md:82-83 of the reference (canonical BPR-MF conf)
 
 
