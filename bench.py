@@ -81,15 +81,16 @@ def pmc_traffic(kernel_prefix, workload):
     return None, None
 
 
-def pmc_fetch_bytes(kernel_prefix, workload):
-    """Fabric-side READ bytes of one launch (FETCH_SIZE x 2, see pmc_traffic) from the committed profile, or None."""
+def pmc_fetch_bytes(kernel_prefix, workload, key=None):
+    """Fabric-side READ bytes of one launch (FETCH_SIZE x 2, see pmc_traffic) from the committed profile, or None;
+    key: another field of that kernel's row instead (e.g. 'l2_hit_rate' = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum))."""
     d = PROFILE_DIR.get(workload)
     path = os.path.join(REPO, 'profiles', d or '', 'pmc_summary.json')
     if not d or not os.path.isfile(path):
         return None
     for name, row in json.load(open(path)).items():
         if name.startswith(kernel_prefix) and 'FETCH_SIZE_KB_mean' in row:
-            return 2.0 * row['FETCH_SIZE_KB_mean'] * 1024.0
+            return row.get(key) if key else 2.0 * row['FETCH_SIZE_KB_mean'] * 1024.0
     return None
 
 
@@ -543,6 +544,7 @@ def roofline_of(workload, r):
             t_mixed = fetch / (ICACHE_GATHER_GBS * 1e9) + (by - fetch) / (L2_GATHER_GBS * 1e9)
             out['mixed_l2_fabric_model'] = {
                 'l2_miss_share': fetch / by, 'floor_us': t_mixed * 1e6, 'frac': t_mixed / (r['fwd_us'] * 1e-6),
+                'l2_hit_rate_counters': pmc_fetch_bytes('k_fwd_part', workload, 'l2_hit_rate'),   # all requests, writes included
                 'pure_gather_frac': (t_mixed / (r['pure_us'] * 1e-6)) if r.get('pure_us') else None,
                 'note': 'arithmetic from the committed profile\'s FETCH_SIZE (x2) and the guide\'s two gather rates; `frac` above, '
                         'against the all-hits L2 rate, stays the quoted roofline fraction'}
